@@ -1,0 +1,95 @@
+"""ctypes binding of oracle/libmsm_ref.so (CPU restatement in C++). TEST INFRASTRUCTURE ONLY."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CURVE_ID = {"bls12_381_g1": 0, "bls12_381_g2": 1, "bn254_snarks_g1": 2, "bn254_snarks_g2": 3, "pallas": 4, "vesta": 5}
+AFF_BYTES = {"bls12_381_g1": 96, "bls12_381_g2": 192, "bn254_snarks_g1": 64, "bn254_snarks_g2": 128, "pallas": 64, "vesta": 64}
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE, "libmsm_ref.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "libmsm_ref.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        vp, sz, i32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64
+        L.oracle_msm.argtypes = [i32, vp, vp, sz, i32, i32, vp]
+        L.oracle_msm.restype = i32
+        L.oracle_fr_from_mont.argtypes = [i32, vp, vp, sz]
+        L.oracle_fr_to_mont.argtypes = [i32, vp, vp, sz]
+        L.oracle_gen_points.argtypes = [i32, u64, sz, sz, vp, i32]
+        L.oracle_scalar_mul.argtypes = [i32, vp, vp, vp]
+        L.oracle_best_bucket_bit_size.argtypes = [sz, i32]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def msm(curve: str, scalars: np.ndarray, points: np.ndarray, nthreads: int = 1, c: int = 0):
+    """scalars: (n,32) u8 canonical LE; points: (n,AFF) u8 Montgomery affine. -> (affine bytes, c used)"""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+    points = np.ascontiguousarray(points, dtype=np.uint8)
+    n = scalars.shape[0]
+    assert points.shape[0] == n
+    out = np.zeros(AFF_BYTES[curve], dtype=np.uint8)
+    used = lib().oracle_msm(CURVE_ID[curve], _ptr(scalars), _ptr(points), n, nthreads, c, _ptr(out))
+    assert used >= 0
+    return out, used
+
+
+def gen_points(curve: str, seed: int, n: int, first: int = 0, nthreads: int = 0) -> np.ndarray:
+    out = np.zeros((n, AFF_BYTES[curve]), dtype=np.uint8)
+    nt = nthreads or (os.cpu_count() or 1)
+    lib().oracle_gen_points(CURVE_ID[curve], seed & (2**64 - 1), first, n, _ptr(out), nt)
+    return out
+
+
+def fr_to_mont(curve: str, a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    out = np.zeros_like(a)
+    lib().oracle_fr_to_mont(CURVE_ID[curve], _ptr(a), _ptr(out), a.shape[0])
+    return out
+
+
+def fr_from_mont(curve: str, a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    out = np.zeros_like(a)
+    lib().oracle_fr_from_mont(CURVE_ID[curve], _ptr(a), _ptr(out), a.shape[0])
+    return out
+
+
+def scalar_mul(curve: str, k: np.ndarray, p: np.ndarray) -> np.ndarray:
+    k = np.ascontiguousarray(k, dtype=np.uint8)
+    p = np.ascontiguousarray(p, dtype=np.uint8)
+    out = np.zeros(AFF_BYTES[curve], dtype=np.uint8)
+    lib().oracle_scalar_mul(CURVE_ID[curve], _ptr(k), _ptr(p), _ptr(out))
+    return out
+
+
+def synth_scalars(seed: int, n: int, bits: int, first: int = 0) -> np.ndarray:
+    """Vectorised pyoracle.synth_scalar: (n,32) u8, uniform in [0,2^bits), not reduced."""
+    idx = (np.arange(first, first + n, dtype=np.uint64)[:, None] * np.uint64(4) + np.arange(4, dtype=np.uint64)[None, :])
+    with np.errstate(over="ignore"):
+        x = idx + np.uint64(seed & (2**64 - 1))
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    top = bits - 192
+    z[:, 3] &= np.uint64((1 << top) - 1)
+    return z.view(np.uint8).reshape(n, 32).copy()

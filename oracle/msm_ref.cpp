@@ -1,0 +1,658 @@
+// oracle/msm_ref.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement ("port") of the reference's variable-time multi-scalar multiplication,
+// used (a) as the parity checker for the HIP engine at sizes Python is too slow for and
+// (b) as bench.py's `cpu_baseline` (kind = "port": Nim is not available in this image, so
+// the reference itself cannot be built -- see DESIGN.md).  Nothing in the product path
+// (constantine_amd/, libctt_msm_hip.so) may link or call this file.
+//
+// Parity status: PINNED -- tests/test_oracle_c.py checks this file against oracle/pyoracle.py,
+// which is itself checked against the reference's golden vectors (tests/golden/*).
+//
+// What is restated, with the reference location it follows (paths relative to the reference root):
+//   Montgomery CIOS multiplication, 64-bit limbs ... constantine/math/arithmetic/limbs_montgomery.nim:180-217
+//   fromMont / getMont .............................. limbs_montgomery.nim:420-441,577-648
+//   modular add/sub/neg/double ....................... constantine/math/arithmetic/finite_fields.nim:172-266
+//   Montgomery constants (m0ninv, R mod p, R^2) ...... constantine/named/deriv/precompute.nim:248-373
+//   Fp2 = Fp[i]/(i^2+1) ............................... constantine/math/extension_fields/towers.nim:758-878
+//   Jacobian double / mixed add / add (a = 0) ........ constantine/math/elliptic/ec_shortweierstrass_jacobian.nim:564-592,655-679,798-896
+//   Booth signed windows ............................. constantine/math/arithmetic/bigints.nim:360-380,806-859
+//   bestBucketBitSize ................................ constantine/math/elliptic/ec_multi_scalar_mul_scheduler.nim:172-223
+//   serial signed-window Pippenger ................... constantine/math/elliptic/ec_multi_scalar_mul.nim:177-296
+//   window-level + msm-level (point sharding) threads  constantine/math/elliptic/ec_multi_scalar_mul_parallel.nim:148-208,386-431,519-553
+//   balanced chunking ................................ constantine/threadpool/partitioners.nim:44-77
+//
+// Deliberate simplification (documented in DESIGN.md): buckets are always Jacobian
+// (the reference switches to batched-affine buckets for c >= 9, scheduler.nim:414-553) and no
+// endomorphism pre-split is applied (ec_multi_scalar_mul.nim:398-432).  Both only change the
+// operation count, never the group element returned.
+//
+// Build: g++ -O3 -march=native -shared -fPIC -pthread oracle/msm_ref.cpp -o oracle/libmsm_ref.so
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+// ------------------------------------------------------------------------------------------
+// Prime fields, N 64-bit limbs, Montgomery form
+// ------------------------------------------------------------------------------------------
+
+template <int N_>
+struct FieldCtx {
+  u64 p[N_];
+  u64 m0inv;     // -p^-1 mod 2^64
+  u64 one[N_];   // R mod p
+  u64 r2[N_];    // R^2 mod p
+  u64 pm2[N_];   // p - 2 (Fermat inversion exponent)
+};
+
+static void hex_to_limbs(const char* hex, u64* out, int n) {
+  memset(out, 0, sizeof(u64) * n);
+  size_t len = strlen(hex);
+  for (size_t i = 0; i < len; i++) {
+    char ch = hex[len - 1 - i];
+    u64 v = (ch >= '0' && ch <= '9') ? ch - '0' : (ch >= 'a' && ch <= 'f') ? ch - 'a' + 10 : ch - 'A' + 10;
+    out[i / 16] |= v << (4 * (i % 16));
+  }
+}
+
+template <int N>
+static inline u64 add_n(u64* r, const u64* a, const u64* b) {
+  u64 c = 0;
+  for (int i = 0; i < N; i++) {
+    u128 s = (u128)a[i] + b[i] + c;
+    r[i] = (u64)s;
+    c = (u64)(s >> 64);
+  }
+  return c;
+}
+template <int N>
+static inline u64 sub_n(u64* r, const u64* a, const u64* b) {
+  u64 bw = 0;
+  for (int i = 0; i < N; i++) {
+    u128 d = (u128)a[i] - b[i] - bw;
+    r[i] = (u64)d;
+    bw = (u64)(d >> 64) & 1;
+  }
+  return bw;
+}
+template <int N>
+static inline bool geq_n(const u64* a, const u64* b) {
+  for (int i = N - 1; i >= 0; i--) {
+    if (a[i] != b[i]) return a[i] > b[i];
+  }
+  return true;
+}
+
+template <class Tag>
+struct Fp {
+  static constexpr int N = Tag::N;
+  static FieldCtx<N> ctx;
+  u64 l[N];
+
+  static void init() {
+    FieldCtx<N>& c = ctx;
+    hex_to_limbs(Tag::modulus(), c.p, N);
+    // m0inv by Newton iteration on 2-adic inverse (precompute.nim "negInvModWord")
+    u64 inv = 1;
+    for (int i = 0; i < 6; i++) inv *= 2 - c.p[0] * inv;
+    c.m0inv = (u64)0 - inv;
+    // R mod p and R^2 mod p by repeated modular doubling of 1
+    u64 t[N];
+    memset(t, 0, sizeof t);
+    t[0] = 1;
+    for (int i = 0; i < 2 * 64 * N; i++) {
+      u64 carry = add_n<N>(t, t, t);
+      if (carry || geq_n<N>(t, c.p)) sub_n<N>(t, t, c.p);
+      if (i == 64 * N - 1) memcpy(c.one, t, sizeof t);
+    }
+    memcpy(c.r2, t, sizeof t);
+    u64 two[N];
+    memset(two, 0, sizeof two);
+    two[0] = 2;
+    sub_n<N>(c.pm2, c.p, two);
+  }
+
+  static Fp zero() { Fp r; memset(r.l, 0, sizeof r.l); return r; }
+  static Fp one() { Fp r; memcpy(r.l, ctx.one, sizeof r.l); return r; }
+  bool is_zero() const { u64 a = 0; for (int i = 0; i < N; i++) a |= l[i]; return a == 0; }
+  bool operator==(const Fp& o) const { return memcmp(l, o.l, sizeof l) == 0; }
+
+  static inline Fp add(const Fp& a, const Fp& b) {
+    Fp r;
+    u64 c = add_n<N>(r.l, a.l, b.l);
+    if (c || geq_n<N>(r.l, ctx.p)) sub_n<N>(r.l, r.l, ctx.p);
+    return r;
+  }
+  static inline Fp sub(const Fp& a, const Fp& b) {
+    Fp r;
+    if (sub_n<N>(r.l, a.l, b.l)) add_n<N>(r.l, r.l, ctx.p);
+    return r;
+  }
+  static inline Fp neg(const Fp& a) {
+    if (a.is_zero()) return a;
+    Fp r;
+    sub_n<N>(r.l, ctx.p, a.l);
+    return r;
+  }
+  static inline Fp dbl(const Fp& a) { return add(a, a); }
+
+  // CIOS, limbs_montgomery.nim:180-217
+  static inline Fp mul(const Fp& a, const Fp& b) {
+    u64 t[N + 2];
+    memset(t, 0, sizeof t);
+    const u64* p = ctx.p;
+    const u64 m0 = ctx.m0inv;
+    for (int i = 0; i < N; i++) {
+      u64 c = 0;
+      for (int j = 0; j < N; j++) {
+        u128 s = (u128)a.l[j] * b.l[i] + t[j] + c;
+        t[j] = (u64)s;
+        c = (u64)(s >> 64);
+      }
+      u128 s = (u128)t[N] + c;
+      t[N] = (u64)s;
+      t[N + 1] = (u64)(s >> 64);
+      u64 m = t[0] * m0;
+      s = (u128)m * p[0] + t[0];
+      c = (u64)(s >> 64);
+      for (int j = 1; j < N; j++) {
+        s = (u128)m * p[j] + t[j] + c;
+        t[j - 1] = (u64)s;
+        c = (u64)(s >> 64);
+      }
+      s = (u128)t[N] + c;
+      t[N - 1] = (u64)s;
+      t[N] = t[N + 1] + (u64)(s >> 64);
+    }
+    Fp r;
+    if (t[N] || geq_n<N>(t, p)) sub_n<N>(r.l, t, p); else memcpy(r.l, t, sizeof r.l);
+    return r;
+  }
+  static inline Fp sqr(const Fp& a) { return mul(a, a); }
+
+  static Fp from_mont(const Fp& a) {  // fromMont: multiply by 1
+    Fp o = zero();
+    o.l[0] = 1;
+    return mul(a, o);
+  }
+  static Fp to_mont(const Fp& a) {  // getMont: multiply by R^2
+    Fp r2;
+    memcpy(r2.l, ctx.r2, sizeof r2.l);
+    return mul(a, r2);
+  }
+  static Fp inv(const Fp& a) {  // a^(p-2); same value as the reference's inv_vartime
+    Fp r = one();
+    for (int i = 64 * N - 1; i >= 0; i--) {
+      r = sqr(r);
+      if ((ctx.pm2[i / 64] >> (i % 64)) & 1) r = mul(r, a);
+    }
+    return r;
+  }
+  static Fp from_u64(u64 v) {
+    Fp r = zero();
+    r.l[0] = v;
+    return to_mont(r);
+  }
+};
+template <class Tag> FieldCtx<Fp<Tag>::N> Fp<Tag>::ctx;
+
+// Fp2 = Fp[i]/(i^2+1), towers.nim:758-878
+template <class F>
+struct Fp2 {
+  F c0, c1;
+  static void init() {}
+  static Fp2 zero() { return {F::zero(), F::zero()}; }
+  static Fp2 one() { return {F::one(), F::zero()}; }
+  bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  bool operator==(const Fp2& o) const { return c0 == o.c0 && c1 == o.c1; }
+  static Fp2 add(const Fp2& a, const Fp2& b) { return {F::add(a.c0, b.c0), F::add(a.c1, b.c1)}; }
+  static Fp2 sub(const Fp2& a, const Fp2& b) { return {F::sub(a.c0, b.c0), F::sub(a.c1, b.c1)}; }
+  static Fp2 neg(const Fp2& a) { return {F::neg(a.c0), F::neg(a.c1)}; }
+  static Fp2 dbl(const Fp2& a) { return add(a, a); }
+  static Fp2 mul(const Fp2& a, const Fp2& b) {  // Karatsuba, prod_complex towers.nim:818-850
+    F v0 = F::mul(a.c0, b.c0), v1 = F::mul(a.c1, b.c1);
+    F s = F::mul(F::add(a.c0, a.c1), F::add(b.c0, b.c1));
+    return {F::sub(v0, v1), F::sub(F::sub(s, v0), v1)};
+  }
+  static Fp2 sqr(const Fp2& a) {  // square_complex towers.nim:758-796
+    F s = F::add(a.c0, a.c1), d = F::sub(a.c0, a.c1);
+    F m = F::mul(a.c0, a.c1);
+    return {F::mul(s, d), F::dbl(m)};
+  }
+  static Fp2 inv(const Fp2& a) {
+    F n = F::inv(F::add(F::sqr(a.c0), F::sqr(a.c1)));
+    return {F::mul(a.c0, n), F::neg(F::mul(a.c1, n))};
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Curves
+// ------------------------------------------------------------------------------------------
+
+template <class F>
+struct Aff { F x, y; bool is_inf() const { return x.is_zero() && y.is_zero(); } };  // neutral = (0,0)
+
+template <class F>
+struct Jac {
+  F x, y, z;
+  static Jac inf() { return {F::one(), F::one(), F::zero()}; }  // jacobian.nim:58-64
+  bool is_inf() const { return z.is_zero(); }
+
+  static Jac from_aff(const Aff<F>& p) {
+    if (p.is_inf()) return inf();
+    return {p.x, p.y, F::one()};
+  }
+
+  // dbl-2009-l, a = 0
+  static Jac dbl(const Jac& p) {
+    if (p.is_inf()) return p;
+    F A = F::sqr(p.x), B = F::sqr(p.y), C = F::sqr(B);
+    F D = F::dbl(F::sub(F::sub(F::sqr(F::add(p.x, B)), A), C));
+    F E = F::add(F::dbl(A), A), Fq = F::sqr(E);
+    Jac r;
+    r.x = F::sub(Fq, F::dbl(D));
+    F C8 = F::dbl(F::dbl(F::dbl(C)));
+    r.z = F::dbl(F::mul(p.y, p.z));
+    r.y = F::sub(F::mul(E, F::sub(D, r.x)), C8);
+    return r;
+  }
+
+  // mixedSum_vartime (jacobian.nim:798-896): handles infinity, P == Q and P == -Q
+  static Jac madd(const Jac& p, const Aff<F>& q, bool negq) {
+    if (q.is_inf()) return p;
+    F qy = negq ? F::neg(q.y) : q.y;
+    if (p.is_inf()) return {q.x, qy, F::one()};
+    F Z1Z1 = F::sqr(p.z);
+    F U2 = F::mul(q.x, Z1Z1);
+    F S2 = F::mul(F::mul(qy, p.z), Z1Z1);
+    F H = F::sub(U2, p.x);
+    F Rr = F::sub(S2, p.y);
+    if (H.is_zero()) {
+      if (Rr.is_zero()) return dbl(p);
+      return inf();
+    }
+    F HH = F::sqr(H), HHH = F::mul(H, HH), V = F::mul(p.x, HH);
+    Jac r;
+    r.x = F::sub(F::sub(F::sqr(Rr), HHH), F::dbl(V));
+    r.y = F::sub(F::mul(Rr, F::sub(V, r.x)), F::mul(p.y, HHH));
+    r.z = F::mul(p.z, H);
+    return r;
+  }
+
+  // sum_vartime (jacobian.nim:655-679 and above)
+  static Jac add(const Jac& p, const Jac& q) {
+    if (p.is_inf()) return q;
+    if (q.is_inf()) return p;
+    F Z1Z1 = F::sqr(p.z), Z2Z2 = F::sqr(q.z);
+    F U1 = F::mul(p.x, Z2Z2), U2 = F::mul(q.x, Z1Z1);
+    F S1 = F::mul(F::mul(p.y, q.z), Z2Z2), S2 = F::mul(F::mul(q.y, p.z), Z1Z1);
+    F H = F::sub(U2, U1), Rr = F::sub(S2, S1);
+    if (H.is_zero()) {
+      if (Rr.is_zero()) return dbl(p);
+      return inf();
+    }
+    F HH = F::sqr(H), HHH = F::mul(H, HH), V = F::mul(U1, HH);
+    Jac r;
+    r.x = F::sub(F::sub(F::sqr(Rr), HHH), F::dbl(V));
+    r.y = F::sub(F::mul(Rr, F::sub(V, r.x)), F::mul(S1, HHH));
+    r.z = F::mul(F::mul(p.z, q.z), H);
+    return r;
+  }
+
+  Aff<F> to_aff() const {
+    if (is_inf()) return {F::zero(), F::zero()};
+    F zi = F::inv(z), zi2 = F::sqr(zi);
+    return {F::mul(x, zi2), F::mul(y, F::mul(zi2, zi))};
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Scalars (BigInt[bits], 4 x u64 LE, canonical) and window recoding
+// ------------------------------------------------------------------------------------------
+
+struct Scalar { u64 l[4]; };
+
+// getWindowAt + signedWindowEncoding, bigints.nim:360-380,806-859
+static inline void booth_digit(const Scalar& k, int w, int c, uint32_t& val, bool& neg) {
+  int i = w * c;
+  u64 d;
+  if (i == 0) {
+    d = (k.l[0] << 1);
+  } else {
+    int pos = i - 1;
+    int slot = pos >> 6, sh = pos & 63;
+    d = slot < 4 ? k.l[slot] >> sh : 0;
+    if (sh + c + 1 > 64 && slot + 1 < 4) d |= k.l[slot + 1] << (64 - sh);
+  }
+  d &= ((u64)1 << (c + 1)) - 1;
+  u64 ng = d >> c;
+  u64 e = (d + 1) >> 1;
+  u64 v = ng ? ((u64)1 << c) - e : e;
+  val = (uint32_t)(v & (((u64)1 << c) - 1));
+  neg = ng != 0;
+}
+
+// scheduler.nim:172-223 (float32, like the reference)
+static int best_bucket_bit_size(size_t n, int bits, bool is_signed, bool manual) {
+  const float A = 10.f, D = 6.f;
+  const int s = is_signed ? 1 : 0;
+  float b = (float)bits, best_cost = INFINITY;
+  int best = 2;
+  for (int c = 2; c <= 20; c++) {
+    float b_over_c = b / (float)c;
+    float acc = b_over_c * (float)((double)n + (double)((u64)1 << (c - s)) - 2.0) * A;
+    float fin = (b_over_c - 1.f) * ((float)c * D + A);
+    float cost = acc + fin;
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  if (manual) {
+    if (best >= 14) best--;
+    if (best >= 15) best--;
+    if (best >= 16) best--;
+  }
+  return best;
+}
+
+// ------------------------------------------------------------------------------------------
+// MSM
+// ------------------------------------------------------------------------------------------
+
+// bucketAccumReduce, ec_multi_scalar_mul.nim:204-235 (accumulate :177-184, bucketReduce :186-197)
+template <class F>
+static Jac<F> window_sum(const Scalar* coefs, const Aff<F>* pts, size_t n, int w, int c, Jac<F>* buckets) {
+  const size_t B = (size_t)1 << (c - 1);
+  for (size_t i = 0; i < B; i++) buckets[i] = Jac<F>::inf();
+  for (size_t j = 0; j < n; j++) {
+    uint32_t val; bool neg;
+    booth_digit(coefs[j], w, c, val, neg);
+    if (val == 0) continue;
+    buckets[val - 1] = Jac<F>::madd(buckets[val - 1], pts[j], neg);
+  }
+  Jac<F> acc = buckets[B - 1], r = buckets[B - 1];
+  for (size_t k = B - 1; k-- > 0;) {
+    acc = Jac<F>::add(acc, buckets[k]);
+    r = Jac<F>::add(r, acc);
+  }
+  return r;
+}
+
+// msmImpl_vartime, ec_multi_scalar_mul.nim:256-296 (serial: windows top -> bottom, one bucket array)
+template <class F>
+static Jac<F> msm_serial(const Scalar* coefs, const Aff<F>* pts, size_t n, int bits, int c) {
+  const int W = bits / c + 1;
+  std::vector<Jac<F>> buckets((size_t)1 << (c - 1));
+  Jac<F> r = Jac<F>::inf();
+  for (int w = W - 1; w >= 0; w--) {
+    for (int k = 0; k < c; k++) r = Jac<F>::dbl(r);
+    r = Jac<F>::add(r, window_sum<F>(coefs, pts, n, w, c, buckets.data()));
+  }
+  return r;
+}
+
+// ec_multi_scalar_mul_parallel.nim:148-208 (one task per window) x :386-431 (msm-level split)
+template <class F>
+static Jac<F> msm_parallel(const Scalar* coefs, const Aff<F>* pts, size_t n, int bits, int c, int nthreads) {
+  const int W = bits / c + 1;
+  int winpar = bits / c, msmpar = 1;
+  while ((long)winpar * msmpar < nthreads) msmpar <<= 1;
+  if ((size_t)msmpar > n) msmpar = 1;
+  // balancedChunksPrioNumber, partitioners.nim:44-77
+  std::vector<size_t> start(msmpar + 1);
+  size_t base = n / msmpar, cutoff = n % msmpar;
+  start[0] = 0;
+  for (int i = 0; i < msmpar; i++) start[i + 1] = start[i] + base + ((size_t)i < cutoff ? 1 : 0);
+
+  const int ntasks = msmpar * W;
+  std::vector<Jac<F>> sums(ntasks);
+  std::atomic<int> next(0);
+  auto worker = [&]() {
+    std::vector<Jac<F>> buckets((size_t)1 << (c - 1));
+    for (;;) {
+      int t = next.fetch_add(1);
+      if (t >= ntasks) break;
+      int chunk = t / W, w = W - 1 - (t % W);
+      sums[chunk * W + w] = window_sum<F>(coefs + start[chunk], pts + start[chunk],
+                                          start[chunk + 1] - start[chunk], w, c, buckets.data());
+    }
+  };
+  std::vector<std::thread> th;
+  for (int i = 1; i < nthreads; i++) th.emplace_back(worker);
+  worker();
+  for (auto& t : th) t.join();
+
+  Jac<F> total = Jac<F>::inf();
+  for (int ch = 0; ch < msmpar; ch++) {
+    Jac<F> r = Jac<F>::inf();
+    for (int w = W - 1; w >= 0; w--) {
+      for (int k = 0; k < c; k++) r = Jac<F>::dbl(r);
+      r = Jac<F>::add(r, sums[ch * W + w]);
+    }
+    total = Jac<F>::add(total, r);
+  }
+  return total;
+}
+
+template <class F>
+static Jac<F> scalar_mul(const Scalar& k, const Aff<F>& p) {
+  Jac<F> r = Jac<F>::inf();
+  for (int i = 255; i >= 0; i--) {
+    r = Jac<F>::dbl(r);
+    if ((k.l[i / 64] >> (i % 64)) & 1) r = Jac<F>::madd(r, p, false);
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Curve table
+// ------------------------------------------------------------------------------------------
+
+struct BlsFpTag { static constexpr int N = 6; static const char* modulus() { return "1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab"; } };
+struct BlsFrTag { static constexpr int N = 4; static const char* modulus() { return "73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001"; } };
+struct BnFpTag { static constexpr int N = 4; static const char* modulus() { return "30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47"; } };
+struct BnFrTag { static constexpr int N = 4; static const char* modulus() { return "30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001"; } };
+struct PallasFpTag { static constexpr int N = 4; static const char* modulus() { return "40000000000000000000000000000000224698fc094cf91b992d30ed00000001"; } };
+struct VestaFpTag { static constexpr int N = 4; static const char* modulus() { return "40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001"; } };
+
+typedef Fp<BlsFpTag> BlsFp;  typedef Fp<BlsFrTag> BlsFr;
+typedef Fp<BnFpTag> BnFp;    typedef Fp<BnFrTag> BnFr;
+typedef Fp<PallasFpTag> PallasFp;  // = Vesta Fr
+typedef Fp<VestaFpTag> VestaFp;    // = Pallas Fr
+
+static std::atomic<bool> g_init(false);
+static void ensure_init() {
+  static std::atomic<int> once(0);
+  int exp = 0;
+  if (once.compare_exchange_strong(exp, 1)) {
+    BlsFp::init(); BlsFr::init(); BnFp::init(); BnFr::init(); PallasFp::init(); VestaFp::init();
+    g_init.store(true);
+  } else {
+    while (!g_init.load()) std::this_thread::yield();
+  }
+}
+
+enum { C_BLS_G1 = 0, C_BLS_G2 = 1, C_BN_G1 = 2, C_BN_G2 = 3, C_PALLAS = 4, C_VESTA = 5 };
+
+static int curve_bits(int id) { return (id == C_BN_G1 || id == C_BN_G2) ? 254 : 255; }
+
+static u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  u64 z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <class F>
+static int do_msm(const void* scalars, const void* points, size_t n, int bits, int nthreads, int c_override, void* out) {
+  const Scalar* k = (const Scalar*)scalars;
+  const Aff<F>* p = (const Aff<F>*)points;
+  Aff<F>* o = (Aff<F>*)out;
+  if (n == 0) { *o = {F::zero(), F::zero()}; return 0; }
+  int c = c_override;
+  if (c <= 0) {
+    c = best_bucket_bit_size(n, bits, true, true);
+    // parallel dispatch uses c-1 for c >= 11 (ec_multi_scalar_mul_parallel.nim:545-551); serial caps at 16
+    if (nthreads > 1 && c >= 11) c -= 1;
+    if (c > 16) c = 16;
+  }
+  Jac<F> r = nthreads > 1 ? msm_parallel<F>(k, p, n, bits, c, nthreads) : msm_serial<F>(k, p, n, bits, c);
+  *o = r.to_aff();
+  return c;
+}
+
+template <class Fr>
+static void fr_from_mont_arr(const void* in, void* out, size_t n) {
+  const Fr* a = (const Fr*)in;
+  Fr* o = (Fr*)out;
+  for (size_t i = 0; i < n; i++) o[i] = Fr::from_mont(a[i]);
+}
+template <class Fr>
+static void fr_to_mont_arr(const void* in, void* out, size_t n) {
+  const Fr* a = (const Fr*)in;
+  Fr* o = (Fr*)out;
+  for (size_t i = 0; i < n; i++) o[i] = Fr::to_mont(a[i]);
+}
+
+// P_i = [s_i]G, s_i = 128-bit synth scalar | 1 (same definition as pyoracle.synth_point)
+template <class F>
+static void gen_points(const Aff<F>& G, u64 seed, size_t first, size_t n, void* out, int nthreads) {
+  Aff<F>* o = (Aff<F>*)out;
+  // fixed-base table: T[w][d] = d * 2^(8w) * G, w < 16, d < 256
+  std::vector<Aff<F>> T(16 * 256);
+  Jac<F> base = Jac<F>::from_aff(G);
+  for (int w = 0; w < 16; w++) {
+    Jac<F> acc = Jac<F>::inf();
+    for (int d = 0; d < 256; d++) {
+      T[w * 256 + d] = acc.to_aff();
+      acc = Jac<F>::add(acc, base);
+    }
+    base = acc;  // 256 * previous base
+  }
+  auto work = [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      u64 s[2];
+      u64 sd = seed ^ 0xA5A5A5A5A5A5A5A5ull;
+      s[0] = splitmix64(sd + 4 * (first + i) + 0) | 1;
+      s[1] = splitmix64(sd + 4 * (first + i) + 1);
+      Jac<F> r = Jac<F>::inf();
+      for (int w = 0; w < 16; w++) {
+        int d = (s[w / 8] >> (8 * (w % 8))) & 0xff;
+        if (d) r = Jac<F>::madd(r, T[w * 256 + d], false);
+      }
+      o[i] = r.to_aff();
+    }
+  };
+  if (nthreads < 1) nthreads = 1;
+  std::vector<std::thread> th;
+  size_t per = (n + nthreads - 1) / nthreads;
+  for (int t = 0; t < nthreads; t++) {
+    size_t lo = t * per, hi = lo + per > n ? n : lo + per;
+    if (lo < hi) th.emplace_back(work, lo, hi);
+  }
+  for (auto& t : th) t.join();
+}
+
+template <class F> static Aff<F> aff_from_u64(u64 x, u64 y) { return {F::from_u64(x), F::from_u64(y)}; }
+
+static BlsFp fp_hex(const char* h) { BlsFp r; hex_to_limbs(h, r.l, 6); return BlsFp::to_mont(r); }
+static BnFp bn_hex(const char* h) { BnFp r; hex_to_limbs(h, r.l, 4); return BnFp::to_mont(r); }
+
+extern "C" {
+
+// returns the window size c used (>0), or <0 on bad curve id. out = affine point in the C-API layout
+// (Montgomery limbs; (0,0) = neutral). Scalars are canonical BigInt[bits] (4 x u64 LE).
+int oracle_msm(int curve, const void* scalars, const void* points, size_t n, int nthreads, int c_override, void* out) {
+  ensure_init();
+  int bits = curve_bits(curve);
+  switch (curve) {
+    case C_BLS_G1: return do_msm<BlsFp>(scalars, points, n, bits, nthreads, c_override, out);
+    case C_BLS_G2: return do_msm<Fp2<BlsFp>>(scalars, points, n, bits, nthreads, c_override, out);
+    case C_BN_G1: return do_msm<BnFp>(scalars, points, n, bits, nthreads, c_override, out);
+    case C_BN_G2: return do_msm<Fp2<BnFp>>(scalars, points, n, bits, nthreads, c_override, out);
+    case C_PALLAS: return do_msm<PallasFp>(scalars, points, n, bits, nthreads, c_override, out);
+    case C_VESTA: return do_msm<VestaFp>(scalars, points, n, bits, nthreads, c_override, out);
+  }
+  return -1;
+}
+
+// Fr Montgomery <-> canonical (batchFromField, finite_fields.nim:915-920)
+int oracle_fr_from_mont(int curve, const void* in, void* out, size_t n) {
+  ensure_init();
+  switch (curve) {
+    case C_BLS_G1: case C_BLS_G2: fr_from_mont_arr<BlsFr>(in, out, n); return 0;
+    case C_BN_G1: case C_BN_G2: fr_from_mont_arr<BnFr>(in, out, n); return 0;
+    case C_PALLAS: fr_from_mont_arr<VestaFp>(in, out, n); return 0;
+    case C_VESTA: fr_from_mont_arr<PallasFp>(in, out, n); return 0;
+  }
+  return -1;
+}
+int oracle_fr_to_mont(int curve, const void* in, void* out, size_t n) {
+  ensure_init();
+  switch (curve) {
+    case C_BLS_G1: case C_BLS_G2: fr_to_mont_arr<BlsFr>(in, out, n); return 0;
+    case C_BN_G1: case C_BN_G2: fr_to_mont_arr<BnFr>(in, out, n); return 0;
+    case C_PALLAS: fr_to_mont_arr<VestaFp>(in, out, n); return 0;
+    case C_VESTA: fr_to_mont_arr<PallasFp>(in, out, n); return 0;
+  }
+  return -1;
+}
+
+// out[i] = [s_i]G for i in [first, first+n): deterministic subgroup points in the C-API affine layout
+int oracle_gen_points(int curve, u64 seed, size_t first, size_t n, void* out, int nthreads) {
+  ensure_init();
+  switch (curve) {
+    case C_BLS_G1: {
+      Aff<BlsFp> G = {fp_hex("17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"),
+                      fp_hex("08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1")};
+      gen_points<BlsFp>(G, seed, first, n, out, nthreads); return 0; }
+    case C_BLS_G2: {
+      Aff<Fp2<BlsFp>> G = {
+        {fp_hex("024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8"),
+         fp_hex("13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e")},
+        {fp_hex("0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801"),
+         fp_hex("0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be")}};
+      gen_points<Fp2<BlsFp>>(G, seed, first, n, out, nthreads); return 0; }
+    case C_BN_G1: gen_points<BnFp>(aff_from_u64<BnFp>(1, 2), seed, first, n, out, nthreads); return 0;
+    case C_BN_G2: {
+      Aff<Fp2<BnFp>> G = {
+        {bn_hex("1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED"),
+         bn_hex("198E9393920D483A7260BFB731FB5D25F1AA493335A9E71297E485B7AEF312C2")},
+        {bn_hex("12C85EA5DB8C6DEB4AAB71808DCB408FE3D1E7690C43D37B4CE6CC0166FA7DAA"),
+         bn_hex("090689D0585FF075EC9E99AD690C3395BC4B313370B38EF355ACDADCD122975B")}};
+      gen_points<Fp2<BnFp>>(G, seed, first, n, out, nthreads); return 0; }
+    case C_PALLAS: {
+      Aff<PallasFp> G = {PallasFp::neg(PallasFp::one()), PallasFp::from_u64(2)};
+      gen_points<PallasFp>(G, seed, first, n, out, nthreads); return 0; }
+    case C_VESTA: {
+      Aff<VestaFp> G = {VestaFp::neg(VestaFp::one()), VestaFp::from_u64(2)};
+      gen_points<VestaFp>(G, seed, first, n, out, nthreads); return 0; }
+  }
+  return -1;
+}
+
+// out = [k]P (affine, C-API layout); k = 4 x u64 LE
+int oracle_scalar_mul(int curve, const void* k, const void* p, void* out) {
+  ensure_init();
+  const Scalar& s = *(const Scalar*)k;
+  switch (curve) {
+    case C_BLS_G1: *(Aff<BlsFp>*)out = scalar_mul<BlsFp>(s, *(const Aff<BlsFp>*)p).to_aff(); return 0;
+    case C_BLS_G2: *(Aff<Fp2<BlsFp>>*)out = scalar_mul<Fp2<BlsFp>>(s, *(const Aff<Fp2<BlsFp>>*)p).to_aff(); return 0;
+    case C_BN_G1: *(Aff<BnFp>*)out = scalar_mul<BnFp>(s, *(const Aff<BnFp>*)p).to_aff(); return 0;
+    case C_BN_G2: *(Aff<Fp2<BnFp>>*)out = scalar_mul<Fp2<BnFp>>(s, *(const Aff<Fp2<BnFp>>*)p).to_aff(); return 0;
+    case C_PALLAS: *(Aff<PallasFp>*)out = scalar_mul<PallasFp>(s, *(const Aff<PallasFp>*)p).to_aff(); return 0;
+    case C_VESTA: *(Aff<VestaFp>*)out = scalar_mul<VestaFp>(s, *(const Aff<VestaFp>*)p).to_aff(); return 0;
+  }
+  return -1;
+}
+
+int oracle_best_bucket_bit_size(size_t n, int bits) { return best_bucket_bit_size(n, bits, true, true); }
+
+}  // extern "C"
