@@ -1,0 +1,148 @@
+// ec.h -- short-Weierstrass (a = 0) group law in extended-Jacobian (XYZZ) coordinates.
+//
+// Device bucket type = the reference's EC_ShortW_JacExt:
+//   constantine/math/elliptic/ec_shortweierstrass_jacobian_extended.nim:30-60  (X,Y,ZZ,ZZZ; x=X/ZZ, y=Y/ZZZ; neutral ZZ=0)
+//   mixedSum_vartime  :258-310   (8M+2S)      -> xyzz_madd
+//   mdouble           :232-256                -> xyzz_mdbl
+//   sum_vartime       :173-230   (12M+2S)     -> xyzz_add
+//   double            :149-171                -> xyzz_dbl
+// Input points are EC_ShortW_Aff with neutral encoded as (0,0) (ec_shortweierstrass_affine.nim:47-62).
+// All exceptional cases (either operand neutral, P == Q, P == -Q) are handled, as the reference's
+// *_vartime formulas do (ec_shortweierstrass_jacobian.nim:798-896).
+#pragma once
+#include "fp.h"
+
+namespace ctt {
+
+template <class F>
+struct Affine {
+  F x, y;
+  CTT_HD bool is_inf() const { return x.is_zero() & y.is_zero(); }
+  CTT_HD static Affine inf() { return {F::zero(), F::zero()}; }
+};
+
+template <class F>
+struct XYZZ {
+  F x, y, zz, zzz;
+  CTT_HD bool is_inf() const { return zz.is_zero(); }
+  CTT_HD static XYZZ inf() { return {F::zero(), F::zero(), F::zero(), F::zero()}; }
+  CTT_HD static XYZZ from_affine(const Affine<F>& p) {
+    if (p.is_inf()) return inf();
+    return {p.x, p.y, F::one(), F::one()};
+  }
+};
+
+// 2*(x,y) for an affine, non-neutral point with y != 0 (y == 0 gives ZZ = 0, i.e. the neutral)
+template <class F>
+CTT_HD XYZZ<F> xyzz_mdbl(const F& x, const F& y) {
+  F U = F::dbl(y);
+  F V = F::sqr(U);
+  F W = F::mul(U, V);
+  F S = F::mul(x, V);
+  F xx = F::sqr(x);
+  F M = F::add(F::dbl(xx), xx);
+  XYZZ<F> r;
+  r.x = F::sub(F::sqr(M), F::dbl(S));
+  r.y = F::sub(F::mul(M, F::sub(S, r.x)), F::mul(W, y));
+  r.zz = V;
+  r.zzz = W;
+  return r;
+}
+
+template <class F>
+CTT_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+  if (p.is_inf()) return p;
+  F U = F::dbl(p.y);
+  F V = F::sqr(U);
+  F W = F::mul(U, V);
+  F S = F::mul(p.x, V);
+  F xx = F::sqr(p.x);
+  F M = F::add(F::dbl(xx), xx);
+  XYZZ<F> r;
+  r.x = F::sub(F::sqr(M), F::dbl(S));
+  r.y = F::sub(F::mul(M, F::sub(S, r.x)), F::mul(W, p.y));
+  r.zz = F::mul(V, p.zz);
+  r.zzz = F::mul(W, p.zzz);
+  return r;
+}
+
+// acc += (neg ? -q : q), q affine
+template <class F>
+CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
+  if (q.is_inf()) return;
+  F qy = F::cneg(q.y, neg);
+  if (acc.is_inf()) {
+    acc.x = q.x;
+    acc.y = qy;
+    acc.zz = F::one();
+    acc.zzz = F::one();
+    return;
+  }
+  F U2 = F::mul(q.x, acc.zz);
+  F S2 = F::mul(qy, acc.zzz);
+  F P = F::sub(U2, acc.x);
+  F R = F::sub(S2, acc.y);
+  if (P.is_zero()) {
+    if (R.is_zero()) {
+      acc = xyzz_mdbl<F>(q.x, qy);
+    } else {
+      acc = XYZZ<F>::inf();
+    }
+    return;
+  }
+  F PP = F::sqr(P);
+  F PPP = F::mul(P, PP);
+  F Q = F::mul(acc.x, PP);
+  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.y, PPP));
+  acc.x = X3;
+  acc.y = Y3;
+  acc.zz = F::mul(acc.zz, PP);
+  acc.zzz = F::mul(acc.zzz, PPP);
+}
+
+// acc += q, both XYZZ
+template <class F>
+CTT_HD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& q) {
+  if (q.is_inf()) return;
+  if (acc.is_inf()) {
+    acc = q;
+    return;
+  }
+  F U1 = F::mul(acc.x, q.zz);
+  F U2 = F::mul(q.x, acc.zz);
+  F S1 = F::mul(acc.y, q.zzz);
+  F S2 = F::mul(q.y, acc.zzz);
+  F P = F::sub(U2, U1);
+  F R = F::sub(S2, S1);
+  if (P.is_zero()) {
+    if (R.is_zero()) {
+      acc = xyzz_dbl<F>(acc);
+    } else {
+      acc = XYZZ<F>::inf();
+    }
+    return;
+  }
+  F PP = F::sqr(P);
+  F PPP = F::mul(P, PP);
+  F Q = F::mul(U1, PP);
+  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+  acc.x = X3;
+  acc.y = Y3;
+  acc.zz = F::mul(F::mul(acc.zz, q.zz), PP);
+  acc.zzz = F::mul(F::mul(acc.zzz, q.zzz), PPP);
+}
+
+// x = X/ZZ, y = Y/ZZZ (fromJacobianExtended_vartime, jacobian_extended.nim:353-379, then affine)
+template <class F>
+CTT_HD Affine<F> xyzz_to_affine(const XYZZ<F>& p) {
+  if (p.is_inf()) return Affine<F>::inf();
+  // one inversion: 1/(ZZ*ZZZ)
+  F i = F::inv(F::mul(p.zz, p.zzz));
+  F izz = F::mul(i, p.zzz);
+  F izzz = F::mul(i, p.zz);
+  return {F::mul(p.x, izz), F::mul(p.y, izzz)};
+}
+
+}  // namespace ctt

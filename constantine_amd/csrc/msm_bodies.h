@@ -1,0 +1,290 @@
+// msm_bodies.h -- per-thread bodies of the MSM kernels + curve descriptors.
+//
+// The MI355X engine replaces the reference's CPU Pippenger
+// (constantine/math/elliptic/ec_multi_scalar_mul.nim:204-296, ..._parallel.nim:148-431) with a
+// sort-then-segmented-reduce pipeline:
+//
+//   digits   Booth signed window digits of every scalar     (bigints.nim:806-859)
+//   hist/scan/scatter   counting sort of (point index, sign) by bucket, per window  [LDS kernels]
+//   accum    every lane sums K consecutive sorted entries into XYZZ accumulators
+//            (mixed add = the reference's `accumulate`, ec_multi_scalar_mul.nim:177-184);
+//            runs fully inside a lane's range go straight to the bucket array, runs that
+//            straddle a lane boundary go to head/tail partial slots
+//   merge    partial slots of one bucket are combined (tree over lanes, log steps)
+//   reduce   sum_k k*B_k per window as a chunked running sum, recursively
+//            (parallel form of bucketReduce, ec_multi_scalar_mul.nim:186-197)
+//   combine  Horner over windows on the host (ec_multi_scalar_mul.nim:250-254)
+//
+// Bodies are __host__ __device__ so that tests/emu can execute exactly this code on the CPU
+// (logic check without a GPU); the product path runs them only as HIP kernels.
+#pragma once
+#include "ec.h"
+
+namespace ctt {
+
+static constexpr uint32_t DIGIT_NONE = 0xffffffffu;
+static constexpr uint32_t KEY_NONE = 0xffffffffu;
+
+// ---------------------------------------------------------------------------------------------
+// Curve descriptors (a = 0 everywhere; only the field, scalar field and scalar width matter for MSM)
+// constantine/named/config_fields_and_curves.nim:116-133,214-229,269-287
+// ---------------------------------------------------------------------------------------------
+struct Bls12381G1 { using F = Fp<BLS12_381_Fp>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 0; };
+struct Bls12381G2 { using F = Fp2<Fp<BLS12_381_Fp>>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 1; };
+struct Bn254G1 { using F = Fp<BN254_Fp>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; };
+struct Bn254G2 { using F = Fp2<Fp<BN254_Fp>>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 3; };
+struct PallasEc { using F = Fp<Pallas_Fp>; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; };
+struct VestaEc { using F = Fp<Vesta_Fp>; using Fr = Fp<Pallas_Fp>; static constexpr int BITS = 255; static constexpr int ID = 5; };
+
+// ---------------------------------------------------------------------------------------------
+// Booth signed digits
+// ---------------------------------------------------------------------------------------------
+// c+1 bits of the 256-bit scalar k starting at bit `pos` (bits >= 256 read as 0)
+CTT_HD uint32_t scalar_bits_at(const uint32_t* k, int pos, int nb) {
+  int word = pos >> 5, sh = pos & 31;
+  uint32_t lo = word < 8 ? k[word] >> sh : 0u;
+  if (sh + nb > 32 && word + 1 < 8) lo |= k[word + 1] << (32 - sh);
+  return lo & ((1u << nb) - 1u);
+}
+
+// digit of window w -> packed ((val-1)<<1 | neg) or DIGIT_NONE when val == 0
+CTT_HD uint32_t booth_digit_packed(const uint32_t* k, int w, int c) {
+  int i = w * c;
+  uint32_t d;
+  if (i == 0) {
+    d = (k[0] << 1) & ((1u << (c + 1)) - 1u);
+  } else {
+    d = scalar_bits_at(k, i - 1, c + 1);
+  }
+  uint32_t neg = d >> c;
+  uint32_t e = (d + 1u) >> 1;
+  uint32_t val = neg ? (1u << c) - e : e;
+  val &= (1u << c) - 1u;
+  return val ? (((val - 1u) << 1) | neg) : DIGIT_NONE;
+}
+
+struct DigitsArgs {
+  const uint32_t* scalars;  // [N][8] canonical
+  uint32_t* digits;         // [W][N]
+  uint32_t N;
+  int c, W;
+};
+CTT_HD void digits_body(const DigitsArgs& a, uint32_t j) {
+  if (j >= a.N) return;
+  const uint32_t* k = a.scalars + 8ull * j;
+  for (int w = 0; w < a.W; w++) a.digits[(uint64_t)w * a.N + j] = booth_digit_packed(k, w, a.c);
+}
+
+// Fr Montgomery -> canonical (batchFromField, finite_fields.nim:915-920)
+template <class Fr>
+CTT_HD void fr_from_mont_body(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t j) {
+  if (j >= n) return;
+  Fr a;
+#pragma unroll
+  for (int i = 0; i < Fr::N; i++) a.l[i] = in[(uint64_t)Fr::N * j + i];
+  a = Fr::from_mont(a);
+#pragma unroll
+  for (int i = 0; i < Fr::N; i++) out[(uint64_t)Fr::N * j + i] = a.l[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bucket accumulation over the sorted entry list
+// ---------------------------------------------------------------------------------------------
+template <class F>
+struct AccumArgs {
+  const uint32_t* entries;       // [W][N]   idx | sign<<31, sorted by bucket within a window
+  const uint32_t* bucket_start;  // [W][B+1] exclusive prefix of bucket sizes; [B] = entries in window
+  const Affine<F>* points;
+  XYZZ<F>* buckets;              // [W][B]   (pre-zeroed = neutral)
+  XYZZ<F>* heads;                // [W][G]
+  XYZZ<F>* tails;                // [W][G]
+  uint32_t* hkey;                // [W][G]
+  uint32_t* tkey;                // [W][G]
+  uint32_t N, B, K, G;
+};
+
+template <class F>
+CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
+  if (g >= a.G) return;
+  const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
+  const uint64_t slot = (uint64_t)w * a.G + g;
+  const uint32_t nw = bs[a.B];
+  const uint64_t p0l = (uint64_t)g * a.K;
+  uint32_t hk = KEY_NONE, tk = KEY_NONE;
+  if (p0l >= nw) {
+    a.hkey[slot] = hk;
+    a.tkey[slot] = tk;
+    return;
+  }
+  const uint32_t p0 = (uint32_t)p0l;
+  const uint32_t p1 = (p0l + a.K < nw) ? p0 + a.K : nw;
+  // bucket containing position p0: bs[lo] <= p0 < bs[hi]
+  uint32_t lo = 0, hi = a.B;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (bs[mid] <= p0) lo = mid; else hi = mid;
+  }
+  uint32_t b = lo;
+  uint32_t bend = bs[b + 1];
+  bool first_run = true;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  const uint32_t* ent = a.entries + (uint64_t)w * a.N;
+  for (uint32_t pos = p0; pos < p1; pos++) {
+    if (pos == bend) {
+      // bucket b is finished inside this lane's range
+      if (first_run && bs[b] < p0) {
+        a.heads[slot] = acc;
+        hk = b;
+      } else {
+        a.buckets[(uint64_t)w * a.B + b] = acc;
+      }
+      first_run = false;
+      acc = XYZZ<F>::inf();
+      b++;
+      while (bs[b + 1] == pos) b++;  // skip empty buckets; terminates because pos < nw
+      bend = bs[b + 1];
+    }
+    uint32_t e = ent[pos];
+    Affine<F> pt = a.points[e & 0x7fffffffu];
+    xyzz_madd<F>(acc, pt, (e >> 31) != 0);
+  }
+  const bool started_before = first_run && bs[b] < p0;
+  const bool ends_after = bend > p1;
+  if (started_before) {
+    a.heads[slot] = acc;
+    hk = b;
+  } else if (ends_after) {
+    a.tails[slot] = acc;
+    tk = b;
+  } else {
+    a.buckets[(uint64_t)w * a.B + b] = acc;
+  }
+  a.hkey[slot] = hk;
+  a.tkey[slot] = tk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Merging the partial sums of buckets that straddle lane ranges
+// ---------------------------------------------------------------------------------------------
+template <class F>
+struct MergeArgs {
+  const uint32_t* bucket_start;
+  XYZZ<F>* buckets;
+  XYZZ<F>* heads;
+  const XYZZ<F>* tails;
+  const uint32_t* hkey;
+  const uint32_t* tkey;
+  const uint32_t* maxcount;  // device word: largest bucket size over all windows
+  uint32_t B, K, G;
+};
+
+// heads[g+1] += tails[g]: a tail is the first piece of a straddling bucket, the next lane's head continues it
+template <class F>
+CTT_HD void merge_tail_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
+  if (g + 1 >= a.G) return;
+  const uint64_t slot = (uint64_t)w * a.G + g;
+  if (a.tkey[slot] == KEY_NONE) return;
+  XYZZ<F> h = a.heads[slot + 1];
+  XYZZ<F> t = a.tails[slot];
+  xyzz_add<F>(h, t);
+  a.heads[slot + 1] = h;
+}
+
+// tree step over the chain of heads of one bucket: heads[g] += heads[g+d] for g-chain_start = 0 mod 2d
+template <class F>
+CTT_HD void merge_step_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint32_t d) {
+  if (g >= a.G) return;
+  // longest possible chain is floor((maxcount-1)/K)+1 heads
+  const uint32_t mc = *a.maxcount;
+  if (mc == 0 || d >= (mc - 1) / a.K + 1) return;
+  const uint64_t slot = (uint64_t)w * a.G + g;
+  const uint32_t b = a.hkey[slot];
+  if (b == KEY_NONE) return;
+  const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
+  const uint32_t s = bs[b] / a.K + 1;
+  const uint32_t e = (bs[b + 1] - 1) / a.K;
+  const uint32_t rel = g - s;
+  if ((rel % (2 * d)) != 0 || g + d > e) return;
+  XYZZ<F> x = a.heads[slot];
+  XYZZ<F> y = a.heads[slot + d];
+  xyzz_add<F>(x, y);
+  a.heads[slot] = x;
+}
+
+// the first head of each chain now holds the bucket sum
+template <class F>
+CTT_HD void merge_final_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
+  if (g >= a.G) return;
+  const uint64_t slot = (uint64_t)w * a.G + g;
+  const uint32_t b = a.hkey[slot];
+  if (b == KEY_NONE) return;
+  const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
+  if (g != bs[b] / a.K + 1) return;
+  a.buckets[(uint64_t)w * a.B + b] = a.heads[slot];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bucket reduction: sum_i (i + wbase) * A[i] + sum_i P[i], one level of the recursion
+// ---------------------------------------------------------------------------------------------
+template <class F>
+struct ReduceArgs {
+  const XYZZ<F>* A_in;   // [W][n_in]
+  const XYZZ<F>* P_in;   // [W][n_in] or nullptr
+  XYZZ<F>* A_out;        // [W][n_out]   s * (chunk sum), weight = chunk index at the next level
+  XYZZ<F>* P_out;        // [W][n_out]   locally weighted sum + plain carry-over
+  uint32_t n_in, n_out;
+  uint32_t s, log2s, wbase;
+};
+
+template <class F>
+CTT_HD void reduce_body(const ReduceArgs<F>& a, uint32_t w, uint32_t t) {
+  if (t >= a.n_out) return;
+  const uint64_t base_in = (uint64_t)w * a.n_in;
+  XYZZ<F> acc = XYZZ<F>::inf(), run = XYZZ<F>::inf(), pl = XYZZ<F>::inf();
+  for (int l = (int)a.s - 1; l >= 0; l--) {
+    const uint64_t idx = (uint64_t)t * a.s + (uint32_t)l;
+    if (idx < a.n_in) {
+      XYZZ<F> x = a.A_in[base_in + idx];
+      xyzz_add<F>(acc, x);
+      if (a.P_in) {
+        XYZZ<F> y = a.P_in[base_in + idx];
+        xyzz_add<F>(pl, y);
+      }
+    }
+    if ((uint32_t)l + a.wbase > 0) xyzz_add<F>(run, acc);
+  }
+  for (uint32_t i = 0; i < a.log2s; i++) acc = xyzz_dbl<F>(acc);
+  xyzz_add<F>(run, pl);
+  a.A_out[(uint64_t)w * a.n_out + t] = acc;
+  a.P_out[(uint64_t)w * a.n_out + t] = run;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic subgroup points for benchmarks/tests: P_i = [s_i]G, s_i = 128-bit splitmix word pair | 1
+// (same definition as oracle/pyoracle.py synth_point; mirrors the distribution of the reference's
+// bench inputs, benchmarks/bench_elliptic_parallel_template.nim:78-102)
+// ---------------------------------------------------------------------------------------------
+CTT_HD uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <class F>
+CTT_HD void gen_point_body(const Affine<F>& G, uint64_t seed, uint64_t first, uint32_t n, Affine<F>* out, uint32_t j) {
+  if (j >= n) return;
+  const uint64_t sd = seed ^ 0xA5A5A5A5A5A5A5A5ull;
+  uint64_t s[2];
+  s[0] = splitmix64(sd + 4 * (first + j) + 0) | 1ull;
+  s[1] = splitmix64(sd + 4 * (first + j) + 1);
+  XYZZ<F> r = XYZZ<F>::inf();
+  for (int i = 127; i >= 0; i--) {
+    r = xyzz_dbl<F>(r);
+    if ((s[i >> 6] >> (i & 63)) & 1ull) xyzz_madd<F>(r, G, false);
+  }
+  out[j] = xyzz_to_affine<F>(r);
+}
+
+}  // namespace ctt

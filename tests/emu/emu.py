@@ -1,0 +1,65 @@
+"""ctypes binding of tests/emu/libmsm_emu.so (CPU emulation of the HIP pipeline). Test-only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CURVE_ID = {"bls12_381_g1": 0, "bls12_381_g2": 1, "bn254_snarks_g1": 2, "bn254_snarks_g2": 3, "pallas": 4, "vesta": 5}
+AFF_BYTES = {"bls12_381_g1": 96, "bls12_381_g2": 192, "bn254_snarks_g1": 64, "bn254_snarks_g2": 128, "pallas": 64, "vesta": 64}
+_lib = None
+
+
+def build():
+    src = os.path.join(HERE, "msm_emu.cpp")
+    out = os.path.join(HERE, "libmsm_emu.so")
+    inc = os.path.join(ROOT, "constantine_amd", "csrc")
+    deps = [src] + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, src, "-o", out])
+    return out
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        vp, sz, i32, u64, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32
+        L.emu_msm.argtypes = [i32, i32, i32, vp, vp, vp, sz, i32, i32, i32, i32, vp]
+        L.emu_gen_points.argtypes = [i32, u64, u64, u32, vp]
+        L.emu_field_op.argtypes = [i32, i32, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def msm(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, K=0, rs_log=0, S=0):
+    coefs = np.ascontiguousarray(coefs, dtype=np.uint8)
+    points = np.ascontiguousarray(points, dtype=np.uint8)
+    n = coefs.shape[0]
+    nco = 2 if out_kind == 0 else 3
+    out = np.zeros(AFF_BYTES[curve] // 2 * nco, dtype=np.uint8)
+    plan = np.zeros(8, dtype=np.int32)
+    rc = lib().emu_msm(CURVE_ID[curve], int(coef_is_fr), out_kind, _p(out), _p(coefs), _p(points), n, c, K, rs_log, S, _p(plan))
+    assert rc == 0
+    return out, plan
+
+
+def gen_points(curve, seed, n, first=0):
+    out = np.zeros((n, AFF_BYTES[curve]), dtype=np.uint8)
+    lib().emu_gen_points(CURVE_ID[curve], seed, first, n, _p(out))
+    return out
+
+
+def field_op(curve, op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = a if b is None else np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.zeros_like(a)
+    lib().emu_field_op(CURVE_ID[curve], op, _p(a), _p(b), _p(out))
+    return out

@@ -1,0 +1,173 @@
+// tests/emu/msm_emu.cpp -- TEST INFRASTRUCTURE ONLY (never shipped, never loaded by constantine_amd).
+//
+// CPU emulator of the HIP pipeline: runs the *same* per-thread bodies (constantine_amd/csrc/msm_bodies.h)
+// and the same host orchestration (msm_pipeline.h) with every "kernel launch" replaced by a loop over
+// (window, thread).  It exists so that the kernel logic (segmented accumulation, partial merging,
+// recursive bucket reduction, Booth digits, plan selection) can be checked against the oracle in the
+// CPU-only container; the LDS counting sort is emulated slice by slice with the same offset scheme.
+// Build: g++ -O2 -std=c++17 -shared -fPIC -I constantine_amd/csrc tests/emu/msm_emu.cpp -o tests/emu/libmsm_emu.so
+#include <algorithm>
+
+#include "msm_pipeline.h"
+
+using namespace ctt;
+
+struct EmuBackend {
+  void* alloc(size_t b) { return malloc(b); }
+  void free(void* p) { ::free(p); }
+  void memset0(void* p, size_t b) { memset(p, 0, b); }
+  void d2h(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
+  void stage_begin(int) {}
+  void stage_end(int) {}
+
+  template <class Fr>
+  void launch_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
+    for (uint32_t j = 0; j < n; j++) fr_from_mont_body<Fr>(in, out, n, j);
+  }
+  void launch_digits(const DigitsArgs& a) {
+    for (uint32_t j = 0; j < a.N; j++) digits_body(a, j);
+  }
+  void launch_sort(const uint32_t* digits, uint32_t* counts, uint32_t* bstart, uint32_t* entries, uint32_t* maxcount,
+                   uint32_t n, uint32_t B, uint32_t S, uint32_t slice, uint32_t W) {
+    for (uint32_t w = 0; w < W; w++) {
+      // hist
+      for (uint32_t s = 0; s < S; s++) {
+        uint32_t* h = counts + ((size_t)w * S + s) * B;
+        memset(h, 0, (size_t)B * 4);
+        uint32_t j1 = std::min(n, (s + 1) * slice);
+        for (uint32_t j = s * slice; j < j1; j++) {
+          uint32_t d = digits[(size_t)w * n + j];
+          if (d != DIGIT_NONE) h[d >> 1]++;
+        }
+      }
+      // scan
+      uint32_t run = 0, mx = 0;
+      for (uint32_t b = 0; b < B; b++) {
+        uint32_t tot = 0;
+        for (uint32_t s = 0; s < S; s++) {
+          uint32_t* p = counts + ((size_t)w * S + s) * B + b;
+          uint32_t v = *p;
+          *p = tot;
+          tot += v;
+        }
+        bstart[(size_t)w * (B + 1) + b] = run;
+        run += tot;
+        mx = std::max(mx, tot);
+      }
+      bstart[(size_t)w * (B + 1) + B] = run;
+      *maxcount = std::max(*maxcount, mx);
+      // scatter
+      for (uint32_t s = 0; s < S; s++) {
+        std::vector<uint32_t> off(B);
+        for (uint32_t b = 0; b < B; b++) off[b] = counts[((size_t)w * S + s) * B + b] + bstart[(size_t)w * (B + 1) + b];
+        uint32_t j1 = std::min(n, (s + 1) * slice);
+        for (uint32_t j = s * slice; j < j1; j++) {
+          uint32_t d = digits[(size_t)w * n + j];
+          if (d != DIGIT_NONE) entries[(size_t)w * n + off[d >> 1]++] = j | ((d & 1u) << 31);
+        }
+      }
+    }
+  }
+  template <class F>
+  void launch_accum(const AccumArgs<F>& a, uint32_t W) {
+    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) accum_body<F>(a, w, g);
+  }
+  template <class F>
+  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W) {
+    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_tail_body<F>(a, w, g);
+  }
+  template <class F>
+  void launch_merge_step(const MergeArgs<F>& a, uint32_t W, uint32_t d) {
+    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_step_body<F>(a, w, g, d);
+  }
+  template <class F>
+  void launch_merge_final(const MergeArgs<F>& a, uint32_t W) {
+    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_final_body<F>(a, w, g);
+  }
+  template <class F>
+  void launch_reduce(const ReduceArgs<F>& a, uint32_t W) {
+    for (uint32_t w = 0; w < W; w++) for (uint32_t t = 0; t < a.n_out; t++) reduce_body<F>(a, w, t);
+  }
+};
+
+template <class C>
+static int emu_msm_t(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n,
+                     int c, int K, int rs_log, int S, int* plan_out) {
+  EmuBackend bk;
+  MsmEngine<C, EmuBackend> eng(bk);
+  eng.opt.c = c;
+  eng.opt.K = K;
+  if (rs_log > 0) eng.opt.rs_log = rs_log;
+  eng.opt.S = S;
+  eng.opt.lanes = 4096;
+  XYZZ<typename C::F> res = eng.run((const uint32_t*)coefs, coef_is_fr != 0, (const Affine<typename C::F>*)points, (uint32_t)n);
+  write_result<typename C::F>(r, res, out_kind);
+  if (plan_out && n) {
+    plan_out[0] = eng.last_plan.c; plan_out[1] = eng.last_plan.W; plan_out[2] = (int)eng.last_plan.K;
+    plan_out[3] = (int)eng.last_plan.G; plan_out[4] = (int)eng.last_plan.S;
+  }
+  return 0;
+}
+
+template <class F>
+static void gen_t(const Affine<F>& G, uint64_t seed, uint64_t first, uint32_t n, void* out) {
+  for (uint32_t j = 0; j < n; j++) gen_point_body<F>(G, seed, first, n, (Affine<F>*)out, j);
+}
+
+#include "generators.h"
+
+// field-level probes: op 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inv  (base field of the curve)
+template <class F>
+static void fop(int op, const void* a, const void* b, void* r) {
+  const F& x = *(const F*)a;
+  const F& y = *(const F*)b;
+  F& o = *(F*)r;
+  switch (op) {
+    case 0: o = F::mul(x, y); break;
+    case 1: o = F::sqr(x); break;
+    case 2: o = F::add(x, y); break;
+    case 3: o = F::sub(x, y); break;
+    case 4: o = F::neg(x); break;
+    case 5: o = F::inv(x); break;
+  }
+}
+
+extern "C" {
+
+int emu_msm(int curve, int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n,
+            int c, int K, int rs_log, int S, int* plan_out) {
+  switch (curve) {
+    case 0: return emu_msm_t<Bls12381G1>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
+    case 1: return emu_msm_t<Bls12381G2>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
+    case 2: return emu_msm_t<Bn254G1>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
+    case 3: return emu_msm_t<Bn254G2>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
+    case 4: return emu_msm_t<PallasEc>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
+    case 5: return emu_msm_t<VestaEc>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
+  }
+  return -1;
+}
+
+int emu_gen_points(int curve, uint64_t seed, uint64_t first, uint32_t n, void* out) {
+  switch (curve) {
+    case 0: gen_t(generator<Bls12381G1>(), seed, first, n, out); return 0;
+    case 1: gen_t(generator<Bls12381G2>(), seed, first, n, out); return 0;
+    case 2: gen_t(generator<Bn254G1>(), seed, first, n, out); return 0;
+    case 3: gen_t(generator<Bn254G2>(), seed, first, n, out); return 0;
+    case 4: gen_t(generator<PallasEc>(), seed, first, n, out); return 0;
+    case 5: gen_t(generator<VestaEc>(), seed, first, n, out); return 0;
+  }
+  return -1;
+}
+
+int emu_field_op(int curve, int op, const void* a, const void* b, void* r) {
+  switch (curve) {
+    case 0: fop<Bls12381G1::F>(op, a, b, r); return 0;
+    case 1: fop<Bls12381G2::F>(op, a, b, r); return 0;
+    case 2: fop<Bn254G1::F>(op, a, b, r); return 0;
+    case 3: fop<Bn254G2::F>(op, a, b, r); return 0;
+    case 4: fop<PallasEc::F>(op, a, b, r); return 0;
+    case 5: fop<VestaEc::F>(op, a, b, r); return 0;
+  }
+  return -1;
+}
+}

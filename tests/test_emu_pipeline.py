@@ -1,0 +1,177 @@
+"""
+Logic check of the HIP pipeline on the CPU: tests/emu runs the SAME per-thread bodies and host
+orchestration as the GPU engine (constantine_amd/csrc/msm_bodies.h, msm_pipeline.h) with kernel launches
+replaced by loops, and is compared with the oracle.  This is not the product path (which is GPU-only);
+the GPU parity tests proper are tests/test_gpu_parity.py.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pyoracle as po
+from tests import _golden
+from tests.emu import emu
+
+ALL = list(po.CURVES)
+G1S = ["bls12_381_g1", "bn254_snarks_g1", "pallas", "vesta"]
+
+
+def _aff(curve, b):
+    return curve.aff_from_bytes(bytes(b))
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_field_ops_vs_python(name):
+    curve = po.CURVES[name]
+    F = curve.F
+    rng = random.Random(5)
+    base = F if F.degree == 1 else F.base
+    p = base.p
+
+    def rnd():
+        pool = [0, 1, p - 1, p - 2, 2, (1 << (p.bit_length() - 1)), rng.randrange(p), rng.randrange(p), rng.randrange(p)]
+        v = rng.choice(pool)
+        return v if F.degree == 1 else (v, rng.choice(pool))
+
+    def enc(v):
+        return np.frombuffer(F.to_mont_bytes(v), dtype=np.uint8)
+
+    for _ in range(60):
+        a, b = rnd(), rnd()
+        assert F.from_mont_bytes(bytes(emu.field_op(name, 0, enc(a), enc(b)))) == F.mul(a, b)
+        assert F.from_mont_bytes(bytes(emu.field_op(name, 1, enc(a)))) == F.sqr(a)
+        assert F.from_mont_bytes(bytes(emu.field_op(name, 2, enc(a), enc(b)))) == F.add(a, b)
+        assert F.from_mont_bytes(bytes(emu.field_op(name, 3, enc(a), enc(b)))) == F.sub(a, b)
+        assert F.from_mont_bytes(bytes(emu.field_op(name, 4, enc(a)))) == F.neg(a)
+    for _ in range(4):
+        a = rnd()
+        if not F.is_zero(a):
+            assert F.from_mont_bytes(bytes(emu.field_op(name, 5, enc(a)))) == F.inv(a)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_gen_points_same_definition(name):
+    a = emu.gen_points(name, 77, 5, first=2)
+    b = cref.gen_points(name, 77, 5, first=2)
+    assert bytes(a.tobytes()) == bytes(b.tobytes())
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 64, 300])
+def test_msm_vs_oracle(name, n):
+    curve = po.CURVES[name]
+    if curve.F.degree == 2 and n > 64:
+        pytest.skip("kept small for Fp2")
+    pts = cref.gen_points(name, 3, n)
+    sc = cref.synth_scalars(4, n, curve.scalar_bits)
+    expect, _ = cref.msm(name, sc, pts)
+    for kw in (dict(), dict(c=3, K=4), dict(c=5, K=8, rs_log=1), dict(c=7, K=4, rs_log=2, S=1)):
+        out, plan = emu.msm(name, sc, pts, **kw)
+        assert bytes(out) == bytes(expect), (kw, plan)
+
+
+@pytest.mark.parametrize("name", G1S)
+def test_msm_medium_default_plan(name):
+    curve = po.CURVES[name]
+    n = 5000
+    pts = cref.gen_points(name, 13, n)
+    sc = cref.synth_scalars(14, n, curve.scalar_bits)
+    expect, _ = cref.msm(name, sc, pts, nthreads=4)
+    out, plan = emu.msm(name, sc, pts)
+    assert bytes(out) == bytes(expect), plan
+    out, plan = emu.msm(name, sc, pts, S=3, K=12)
+    assert bytes(out) == bytes(expect), plan
+
+
+def test_window_sizes_including_divisors_of_bits():
+    """c | bits needs the extra top window (ec_multi_scalar_mul.nim:278-289); 255 = 3*5*17, 254 = 2*127."""
+    for name, cs in (("bls12_381_g1", (3, 5, 15, 16)), ("bn254_snarks_g1", (2, 13, 16))):
+        curve = po.CURVES[name]
+        n = 200
+        pts = cref.gen_points(name, 31, n)
+        sc = cref.synth_scalars(32, n, curve.scalar_bits)
+        # force the top bits on for some scalars
+        sc[:20, 31] |= 0x7F if curve.scalar_bits == 255 else 0x3F
+        sc[:20, 24:31] = 0xFF
+        expect, _ = cref.msm(name, sc, pts)
+        for c in cs:
+            out, plan = emu.msm(name, sc, pts, c=c, K=8)
+            assert bytes(out) == bytes(expect), (name, c)
+
+
+def test_all_equal_scalars_long_chains():
+    """Every point lands in the same bucket per window: exercises tail/head chains and the merge tree."""
+    name = "bls12_381_g1"
+    curve = po.CURVES[name]
+    n = 700
+    pts = cref.gen_points(name, 41, n)
+    sc = np.tile(cref.synth_scalars(42, 1, 255), (n, 1))
+    expect, _ = cref.msm(name, sc, pts)
+    for K in (4, 8, 28, 64):
+        out, plan = emu.msm(name, sc, pts, c=6, K=K)
+        assert bytes(out) == bytes(expect), K
+
+
+def test_all_equal_points_and_scalars_doubling_paths():
+    """bug-366 style (t_ec_shortw_jac_g2_msm_bug_366.nim): all points equal -> P == Q adds everywhere."""
+    name = "bn254_snarks_g1"
+    curve = po.CURVES[name]
+    n = 257
+    pts = np.tile(cref.gen_points(name, 51, 1), (n, 1))
+    sc = cref.synth_scalars(52, n, 254)
+    expect, _ = cref.msm(name, sc, pts)
+    out, _ = emu.msm(name, sc, pts, c=4, K=4)
+    assert bytes(out) == bytes(expect)
+    sc2 = np.tile(sc[:1], (n, 1))
+    expect, _ = cref.msm(name, sc2, pts)
+    out, _ = emu.msm(name, sc2, pts, c=5, K=8)
+    assert bytes(out) == bytes(expect)
+
+
+def test_infinity_inputs_cancellation_and_zero_scalars():
+    name = "bls12_381_g1"
+    curve = po.CURVES[name]
+    G = curve.gen
+    pts = curve.points_to_array([G, None, G, curve.neg(G), G, None])
+    sc = curve.scalars_to_array([5, 77, 5, 3, 0, 0])
+    out, _ = emu.msm(name, sc, pts, c=3, K=4)
+    assert _aff(curve, out) == curve.scalar_mul(7, G)
+    pts = curve.points_to_array([G, curve.neg(G)])
+    sc = curve.scalars_to_array([9, 9])
+    out, _ = emu.msm(name, sc, pts, out_kind=0)
+    assert _aff(curve, out) is None
+    jac, _ = emu.msm(name, sc, pts, out_kind=1)
+    assert curve.jac_from_bytes(bytes(jac)) is None
+    prj, _ = emu.msm(name, sc, pts, out_kind=2)
+    assert curve.prj_from_bytes(bytes(prj)) is None
+    # all-zero scalars, n == 0
+    out, _ = emu.msm(name, curve.scalars_to_array([0, 0, 0]), curve.points_to_array([G, G, G]))
+    assert _aff(curve, out) is None
+    out, _ = emu.msm(name, np.zeros((0, 32), np.uint8), np.zeros((0, 96), np.uint8))
+    assert _aff(curve, out) is None
+
+
+@pytest.mark.parametrize("group,cname", [("g1", "bls12_381_g1"), ("g2", "bls12_381_g2")])
+def test_eip2537_golden(group, cname):
+    curve = po.CURVES[cname]
+    for name, scalars, points, expected in _golden.eip2537(group):
+        sc = curve.scalars_to_array([k % curve.order for k in scalars])
+        pts = curve.points_to_array(points)
+        for ok, dec in ((1, curve.jac_from_bytes), (2, curve.prj_from_bytes)):
+            out, _ = emu.msm(cname, sc, pts, out_kind=ok)
+            assert dec(bytes(out)) == expected, name
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_snarks_g1", "pallas"])
+def test_fr_coefs_entry(name):
+    curve = po.CURVES[name]
+    n = 50
+    pts = cref.gen_points(name, 61, n)
+    ks = [po.synth_scalar(62, i, 256) % curve.Fr.p for i in range(n)]
+    can = curve.scalars_to_array(ks)
+    mont = curve.fr_scalars_to_array(ks)
+    expect, _ = cref.msm(name, can, pts)
+    out, _ = emu.msm(name, mont, pts, coef_is_fr=True, c=4)
+    assert bytes(out) == bytes(expect)
