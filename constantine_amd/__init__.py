@@ -1,0 +1,17 @@
+"""
+constantine_amd -- MI355X-native multi-scalar-multiplication engine behind Constantine's MSM API.
+
+Only what the MSM hot path needs lives here:
+  csrc/     HIP kernels (gfx950) + the C ABI  (include/ctt_msm_hip.h)  -> libctt_msm_hip.so
+  _lib.py   ctypes loader (fails loudly if the HIP library is missing)
+  msm.py    host-side mirror of the reference's entry points (multiScalarMul_vartime[_parallel],
+            Halo2-ZAL CttEngine.msm) over the C ABI
+  parallel.py  point-sharded multi-GPU MSM (one process per GPU, torch.distributed / RCCL)
+"""
+from .curves import CURVES, CurveInfo  # noqa: F401
+from .msm import (  # noqa: F401
+    CttEngine,
+    DeviceMsm,
+    multiScalarMul_vartime,
+    multiScalarMul_vartime_parallel,
+)

@@ -1,0 +1,64 @@
+"""ctypes loader for libctt_msm_hip.so. The product path has no fallback: a missing library is an error."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libctt_msm_hip.so")
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Every symbol include/ctt_msm_hip.h declares."""
+    syms = []
+    for stem, par in (("bls12_381_g1", True), ("bls12_381_g2", False), ("bn254_snarks_g1", True),
+                      ("bn254_snarks_g2", False), ("pallas_ec", True), ("vesta_ec", True)):
+        for coord in ("jac", "prj"):
+            for coef in ("big", "fr"):
+                syms.append(f"ctt_{stem}_{coord}_multi_scalar_mul_{coef}_coefs_vartime")
+                if par:
+                    syms.append(f"ctt_{stem}_{coord}_multi_scalar_mul_{coef}_coefs_vartime_parallel")
+    syms += ["ctt_hip_msm_abi_version", "ctt_hip_msm_ctx_create", "ctt_hip_msm_ctx_destroy", "ctt_hip_msm_set_option",
+             "ctt_hip_msm_device", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
+             "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream"]
+    return syms
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C constantine_amd/csrc). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
+    for name in exported_symbols():
+        fn = getattr(L, name)  # AttributeError if the library does not export what the header declares
+        if name.endswith("_vartime"):
+            fn.argtypes = [vp, vp, vp, sz]
+            fn.restype = None
+        elif name.endswith("_vartime_parallel"):
+            fn.argtypes = [vp, vp, vp, vp, sz]
+            fn.restype = None
+    L.ctt_hip_msm_abi_version.restype = i32
+    L.ctt_hip_msm_ctx_create.argtypes = [i32]
+    L.ctt_hip_msm_ctx_create.restype = vp
+    L.ctt_hip_msm_ctx_destroy.argtypes = [vp]
+    L.ctt_hip_msm_ctx_destroy.restype = None
+    L.ctt_hip_msm_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+    L.ctt_hip_msm_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz]
+    L.ctt_hip_msm_last_timings.argtypes = [vp, vp, i32]
+    L.ctt_hip_msm_last_plan.argtypes = [vp, vp, i32]
+    L.ctt_hip_gen_points.argtypes = [vp, i32, u64, u64, u32, vp]
+    L.ctt_hip_field_op.argtypes = [vp, i32, i32, vp, vp, vp, u32]
+    L.ctt_hip_ec_sum_affine.argtypes = [i32, i32, vp, vp, sz]
+    L.ctt_hip_msm_stream.argtypes = [vp]
+    L.ctt_hip_msm_stream.restype = vp
+    _lib = L
+    return L

@@ -1,0 +1,3 @@
+// curve_bn254_snarks_g2.hip -- instantiates the MSM kernels and engine for Bn254G2 (one TU per curve keeps builds parallel).
+#include "hip_backend.h"
+extern "C" const ctt::CurveOps* ctt_ops_bn254_snarks_g2(void) { return ctt::CurveImpl<ctt::Bn254G2>::ops(); }

@@ -50,7 +50,7 @@ CTT_HD XYZZ<F> xyzz_mdbl(const F& x, const F& y) {
 }
 
 template <class F>
-CTT_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+CTT_HD_NOINLINE XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
   if (p.is_inf()) return p;
   F U = F::dbl(p.y);
   F V = F::sqr(U);
@@ -64,6 +64,16 @@ CTT_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
   r.zz = F::mul(V, p.zz);
   r.zzz = F::mul(W, p.zzz);
   return r;
+}
+
+// exceptional case of the mixed addition: same x. equal -> doubling of the affine point, opposite -> neutral
+template <class F>
+CTT_HD_NOINLINE void xyzz_madd_same_x(XYZZ<F>& acc, const F& qx, const F& qy, bool same_y) {
+  if (same_y) {
+    acc = xyzz_mdbl<F>(qx, qy);
+  } else {
+    acc = XYZZ<F>::inf();
+  }
 }
 
 // acc += (neg ? -q : q), q affine
@@ -82,12 +92,8 @@ CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
   F S2 = F::mul(qy, acc.zzz);
   F P = F::sub(U2, acc.x);
   F R = F::sub(S2, acc.y);
-  if (P.is_zero()) {
-    if (R.is_zero()) {
-      acc = xyzz_mdbl<F>(q.x, qy);
-    } else {
-      acc = XYZZ<F>::inf();
-    }
+  if (P.is_zero()) {  // P == +-Q: rare, out of line
+    xyzz_madd_same_x<F>(acc, q.x, qy, R.is_zero());
     return;
   }
   F PP = F::sqr(P);
@@ -101,9 +107,9 @@ CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
   acc.zzz = F::mul(acc.zzz, PPP);
 }
 
-// acc += q, both XYZZ
+// acc += q, both XYZZ  (not on the hot path: kept out of line to bound code size / compile time)
 template <class F>
-CTT_HD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& q) {
+CTT_HD_NOINLINE void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& q) {
   if (q.is_inf()) return;
   if (acc.is_inf()) {
     acc = q;

@@ -21,8 +21,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define CTT_HD __host__ __device__ __forceinline__
+#define CTT_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define CTT_HD inline __attribute__((always_inline))
+#define CTT_HD_NOINLINE __attribute__((noinline))
 #endif
 
 #include "field_params.h"

@@ -1,0 +1,223 @@
+// hip_backend.h -- HIP launch layer shared by the per-curve translation units (curve_*.hip) and the
+// engine (msm_engine.hip): stream, stage events, EC kernel templates, per-curve operation table.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "generators.h"
+#include "msm_pipeline.h"
+
+namespace ctt {
+
+#define HIP_CHECK(expr)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) {                                                                          \
+      fprintf(stderr, "[ctt_msm_hip] FATAL %s:%d: %s -> %s\n", __FILE__, __LINE__, #expr,            \
+              hipGetErrorString(e_));                                                                \
+      abort();                                                                                       \
+    }                                                                                                \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Kernel templates (instantiated per curve in curve_*.hip)
+// ---------------------------------------------------------------------------------------------
+template <class Fr>
+__global__ void k_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
+  fr_from_mont_body<Fr>(in, out, n, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// --- EC kernels: one lane = one body invocation ----------------------------------------------------
+static constexpr int ACCUM_BLOCK = 64;
+static constexpr int EC_BLOCK = 64;
+
+template <class F>
+__global__ void __launch_bounds__(ACCUM_BLOCK) k_accum(AccumArgs<F> a) {
+  accum_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_tail(MergeArgs<F> a) {
+  merge_tail_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_step(MergeArgs<F> a, uint32_t d) {
+  merge_step_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, d);
+}
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_final(MergeArgs<F> a) {
+  merge_final_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_reduce(ReduceArgs<F> a) {
+  reduce_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
+template <class C>
+__global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t first, uint32_t n, Affine<typename C::F>* out) {
+  Affine<typename C::F> G = generator<C>();
+  gen_point_body<typename C::F>(G, seed, first, n, out, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// field-op probe for the GPU unit tests: op 0 mul, 1 sqr, 2 add, 3 sub, 4 neg
+template <class F>
+__global__ void k_field_op(int op, const F* a, const F* b, F* r, uint32_t n) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  F x = a[j], y = b[j], o;
+  switch (op) {
+    case 0: o = F::mul(x, y); break;
+    case 1: o = F::sqr(x); break;
+    case 2: o = F::add(x, y); break;
+    case 3: o = F::sub(x, y); break;
+    default: o = F::neg(x); break;
+  }
+  r[j] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HIP backend
+// ---------------------------------------------------------------------------------------------
+struct HipBackend {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cu = 256;
+  hipEvent_t ev_begin[ST_COUNT], ev_end[ST_COUNT];
+  bool ev_used[ST_COUNT];
+  float stage_ms[ST_COUNT];
+
+  void init(int dev);  // msm_engine.hip
+
+  void* alloc(size_t b) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, b));
+    return p;
+  }
+  void free(void* p) { HIP_CHECK(hipFree(p)); }
+  void memset0(void* p, size_t b) { HIP_CHECK(hipMemsetAsync(p, 0, b, stream)); }
+  void d2h(void* dst, const void* src, size_t b) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void stage_begin(int s) {
+    HIP_CHECK(hipEventRecord(ev_begin[s], stream));
+    ev_used[s] = true;
+  }
+  void stage_end(int s) { HIP_CHECK(hipEventRecord(ev_end[s], stream)); }
+  void collect_timings() {
+    for (int i = 0; i < ST_COUNT; i++) {
+      if (!ev_used[i]) continue;
+      HIP_CHECK(hipEventSynchronize(ev_end[i]));
+      HIP_CHECK(hipEventElapsedTime(&stage_ms[i], ev_begin[i], ev_end[i]));
+    }
+  }
+
+  template <class F>
+  uint32_t resident_lanes() {
+    int nb = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_accum<F>, ACCUM_BLOCK, 0));
+    if (nb < 1) nb = 1;
+    return (uint32_t)nb * ACCUM_BLOCK * (uint32_t)num_cu;
+  }
+
+  static dim3 grid1(uint32_t n, int block) { return dim3((n + block - 1) / block); }
+  static dim3 grid2(uint32_t n, int block, uint32_t W) { return dim3((n + block - 1) / block, W); }
+
+  template <class Fr>
+  void launch_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
+    hipLaunchKernelGGL(k_fr_from_mont<Fr>, grid1(n, 256), dim3(256), 0, stream, in, out, n);
+    HIP_CHECK(hipGetLastError());
+  }
+  void launch_digits(const DigitsArgs& a);  // msm_engine.hip
+  void launch_sort(const uint32_t* digits, uint32_t* counts, uint32_t* bstart, uint32_t* entries, uint32_t* maxcount,
+                   uint32_t n, uint32_t B, uint32_t S, uint32_t slice, uint32_t W);  // msm_engine.hip
+  template <class F>
+  void launch_accum(const AccumArgs<F>& a, uint32_t W) {
+    hipLaunchKernelGGL(k_accum<F>, grid2(a.G, ACCUM_BLOCK, W), dim3(ACCUM_BLOCK), 0, stream, a);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F>
+  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W) {
+    hipLaunchKernelGGL(k_merge_tail<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F>
+  void launch_merge_step(const MergeArgs<F>& a, uint32_t W, uint32_t d) {
+    hipLaunchKernelGGL(k_merge_step<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, d);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F>
+  void launch_merge_final(const MergeArgs<F>& a, uint32_t W) {
+    hipLaunchKernelGGL(k_merge_final<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F>
+  void launch_reduce(const ReduceArgs<F>& a, uint32_t W) {
+    hipLaunchKernelGGL(k_reduce<F>, grid2(a.n_out, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
+    HIP_CHECK(hipGetLastError());
+  }
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// Per-curve operation table: each curve_*.hip instantiates the templates once and exports one of these
+// ---------------------------------------------------------------------------------------------
+struct CurveOps {
+  int curve_id;
+  size_t aff_bytes;
+  void* (*engine_create)(HipBackend* bk);
+  void (*engine_destroy)(void* eng);
+  // runs one MSM on device-resident inputs, writes r (host) in out_kind coordinates, fills plan[6]
+  void (*run)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
+              void* r_host, int out_kind, int* plan);
+  void (*gen_points)(HipBackend* bk, uint64_t seed, uint64_t first, uint32_t n, void* d_out);
+  void (*field_op)(HipBackend* bk, int op, const void* d_a, const void* d_b, void* d_r, uint32_t n);
+  // host-only: r_aff = sum of n affine points (combining the per-GPU partial results of a sharded MSM,
+  // the `r ~+= partial` of ec_multi_scalar_mul_parallel.nim:427-429)
+  void (*ec_sum_affine)(const void* pts_aff, size_t n, void* r_host, int out_kind);
+};
+
+template <class C>
+struct CurveImpl {
+  using F = typename C::F;
+  using Engine = MsmEngine<C, HipBackend>;
+  static void* create(HipBackend* bk) {
+    Engine* e = new Engine(*bk);
+    e->opt.lanes = bk->template resident_lanes<F>();
+    return e;
+  }
+  static void destroy(void* e) { delete (Engine*)e; }
+  static void run(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
+                  void* r_host, int out_kind, int* plan) {
+    Engine& e = *(Engine*)eng;
+    uint32_t lanes = e.opt.lanes;
+    e.opt = *opt;
+    e.opt.lanes = lanes;
+    XYZZ<F> res = e.run((const uint32_t*)d_coefs, coef_is_fr != 0, (const Affine<F>*)d_points, n);
+    const MsmPlan& p = e.last_plan;
+    plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
+    write_result<F>(r_host, res, out_kind);
+  }
+  static void gen_points(HipBackend* bk, uint64_t seed, uint64_t first, uint32_t n, void* d_out) {
+    hipLaunchKernelGGL(k_gen_points<C>, dim3((n + EC_BLOCK - 1) / EC_BLOCK), dim3(EC_BLOCK), 0, bk->stream, seed, first, n,
+                       (Affine<F>*)d_out);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(bk->stream));
+  }
+  static void field_op(HipBackend* bk, int op, const void* d_a, const void* d_b, void* d_r, uint32_t n) {
+    hipLaunchKernelGGL(k_field_op<F>, dim3((n + 255) / 256), dim3(256), 0, bk->stream, op, (const F*)d_a, (const F*)d_b,
+                       (F*)d_r, n);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(bk->stream));
+  }
+  static void ec_sum_affine(const void* pts_aff, size_t n, void* r_host, int out_kind) {
+    const Affine<F>* p = (const Affine<F>*)pts_aff;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = 0; i < n; i++) xyzz_madd<F>(acc, p[i], false);
+    write_result<F>(r_host, acc, out_kind);
+  }
+  static const CurveOps* ops() {
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, run, gen_points, field_op, ec_sum_affine};
+    return &o;
+  }
+};
+
+}  // namespace ctt

@@ -1,0 +1,162 @@
+"""
+Host-side mirror of the reference's MSM entry points, over the C ABI of libctt_msm_hip.so.
+
+Names and argument meaning follow the reference:
+  multiScalarMul_vartime(r, coefs, points)                 constantine/math/elliptic/ec_multi_scalar_mul.nim:525-568
+  multiScalarMul_vartime_parallel(tp, r, coefs, points)    constantine/math/elliptic/ec_multi_scalar_mul_parallel.nim:588-639
+  CttEngine.msm(coeffs, bases)                             constantine-rust/constantine-halo2-zal/src/lib.rs:22-58
+    (Halo2-ZAL MsmAccel: BN254 G1, Fr coefficients, projective result; descriptors at lib.rs:60-95)
+
+Arrays are numpy uint8 buffers in the C-API memory layout (include/ctt_msm_hip.h): coefs (n,32) --
+BigInt canonical little-endian, or Fr Montgomery when fr_coefs=True -- and points (n, 2*coord) affine
+Montgomery.  Like the reference, nothing is validated (no on-curve / subgroup checks) and the functions are
+variable-time: public inputs only.  coefs and points must have the same length (the reference asserts it in
+debug builds, ec_multi_scalar_mul.nim:536).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .curves import COEF_BIG, COEF_FR, CURVES, OUT_AFF, OUT_JAC, OUT_PRJ
+
+_COORD = {"jac": OUT_JAC, "prj": OUT_PRJ, "aff": OUT_AFF}
+
+
+def _check(curve, coefs, points):
+    info = CURVES[curve]
+    coefs = np.ascontiguousarray(coefs, dtype=np.uint8)
+    points = np.ascontiguousarray(points, dtype=np.uint8)
+    if coefs.ndim != 2 or coefs.shape[1] != 32:
+        raise ValueError("coefs must have shape (n, 32)")
+    if points.ndim != 2 or points.shape[1] != info.aff_bytes:
+        raise ValueError(f"points must have shape (n, {info.aff_bytes})")
+    if coefs.shape[0] != points.shape[0]:
+        raise ValueError("coefs and points must have the same length")
+    return info, coefs, points
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def multiScalarMul_vartime(curve, coefs, points, coord="jac", fr_coefs=False):
+    """r <- sum coefs[i]*points[i], via ctt_<curve>_<coord>_multi_scalar_mul_{big,fr}_coefs_vartime.
+    Returns r as a uint8 array of 3 coordinates (X,Y,Z) in `coord` ("jac" or "prj")."""
+    info, coefs, points = _check(curve, coefs, points)
+    L = _lib.lib()
+    fn = getattr(L, f"ctt_{info.sym}_{coord}_multi_scalar_mul_{'fr' if fr_coefs else 'big'}_coefs_vartime")
+    r = np.zeros(info.jac_bytes, dtype=np.uint8)
+    fn(_ptr(r), _ptr(coefs), _ptr(points), coefs.shape[0])
+    return r
+
+
+def multiScalarMul_vartime_parallel(tp, curve, coefs, points, coord="jac", fr_coefs=False):
+    """Same through the *_vartime_parallel symbol; `tp` (a ctt_threadpool* or None) is accepted and ignored,
+    the GPU replaces the pool.  Groups without an upstream parallel symbol (G2) raise AttributeError."""
+    info, coefs, points = _check(curve, coefs, points)
+    if not info.has_parallel:
+        raise AttributeError(f"the reference exports no *_vartime_parallel MSM for {curve}")
+    L = _lib.lib()
+    fn = getattr(L, f"ctt_{info.sym}_{coord}_multi_scalar_mul_{'fr' if fr_coefs else 'big'}_coefs_vartime_parallel")
+    r = np.zeros(info.jac_bytes, dtype=np.uint8)
+    fn(ctypes.c_void_p(tp or 0), _ptr(r), _ptr(coefs), _ptr(points), coefs.shape[0])
+    return r
+
+
+class DeviceMsm:
+    """Device-resident MSM: inputs already in HBM (torch CUDA tensors or raw device pointers)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.lib()
+        self.device = device
+        self.ctx = self.L.ctt_hip_msm_ctx_create(device)
+        if not self.ctx:
+            raise RuntimeError("ctt_hip_msm_ctx_create failed")
+
+    def close(self):
+        if self.ctx:
+            self.L.ctt_hip_msm_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def set_option(self, key, value):
+        if self.L.ctt_hip_msm_set_option(self.ctx, key.encode(), int(value)) != 0:
+            raise KeyError(key)
+
+    @staticmethod
+    def _dptr(t):
+        return ctypes.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+
+    def msm(self, curve, d_coefs, d_points, n, coord="aff", fr_coefs=False):
+        info = CURVES[curve]
+        nco = 2 if coord == "aff" else 3
+        r = np.zeros(nco * info.coord_bytes, dtype=np.uint8)
+        rc = self.L.ctt_hip_msm_device(self.ctx, info.cid, COEF_FR if fr_coefs else COEF_BIG, _COORD[coord], _ptr(r),
+                                       self._dptr(d_coefs), self._dptr(d_points), n)
+        if rc != 0:
+            raise RuntimeError("ctt_hip_msm_device failed")
+        return r
+
+    def gen_points(self, curve, seed, n, d_out, first=0):
+        rc = self.L.ctt_hip_gen_points(self.ctx, CURVES[curve].cid, seed & (2**64 - 1), first, n, self._dptr(d_out))
+        if rc != 0:
+            raise RuntimeError("ctt_hip_gen_points failed")
+
+    def field_op(self, curve, op, d_a, d_b, d_r, n):
+        rc = self.L.ctt_hip_field_op(self.ctx, CURVES[curve].cid, op, self._dptr(d_a), self._dptr(d_b), self._dptr(d_r), n)
+        if rc != 0:
+            raise RuntimeError("ctt_hip_field_op failed")
+
+    def last_timings(self):
+        ms = np.zeros(6, dtype=np.float32)
+        self.L.ctt_hip_msm_last_timings(self.ctx, _ptr(ms), 6)
+        return dict(zip(("digits", "sort", "accumulate", "merge", "reduce", "total"), (float(x) for x in ms)))
+
+    def last_plan(self):
+        p = np.zeros(6, dtype=np.int32)
+        self.L.ctt_hip_msm_last_plan(self.ctx, _ptr(p), 6)
+        return dict(zip(("c", "W", "K", "G", "S", "lanes"), (int(x) for x in p)))
+
+
+def ec_sum_affine(curve, pts_aff, coord="aff"):
+    """Host-only sum of affine points (combining per-GPU partial MSMs)."""
+    info = CURVES[curve]
+    pts = np.ascontiguousarray(pts_aff, dtype=np.uint8).reshape(-1, info.aff_bytes)
+    nco = 2 if coord == "aff" else 3
+    r = np.zeros(nco * info.coord_bytes, dtype=np.uint8)
+    rc = _lib.lib().ctt_hip_ec_sum_affine(info.cid, _COORD[coord], _ptr(r), _ptr(pts), pts.shape[0])
+    if rc != 0:
+        raise RuntimeError("ctt_hip_ec_sum_affine failed")
+    return r
+
+
+class CttEngine:
+    """Mirror of the Halo2-ZAL engine (constantine-halo2-zal/src/lib.rs:22-96): BN254-Snarks G1,
+    coefficients are Fr elements in Montgomery form, result is a projective point."""
+
+    CURVE = "bn254_snarks_g1"
+
+    def __init__(self, num_threads=0):
+        self.num_threads = num_threads  # kept for signature parity; the GPU path has no thread pool
+
+    def msm(self, coeffs, bases):
+        # lib.rs:42-58 -> ctt_bn254_snarks_g1_prj_multi_scalar_mul_fr_coefs_vartime_parallel
+        if len(coeffs) != len(bases):
+            raise AssertionError("coeffs and bases must have the same length")  # assert_eq! at lib.rs:43
+        return multiScalarMul_vartime_parallel(None, self.CURVE, coeffs, bases, coord="prj", fr_coefs=True)
+
+    # descriptor API (lib.rs:60-95): pass-throughs upstream; here they pin the arrays as-is
+    def get_coeffs_descriptor(self, coeffs):
+        return np.ascontiguousarray(coeffs, dtype=np.uint8)
+
+    def get_base_descriptor(self, bases):
+        return np.ascontiguousarray(bases, dtype=np.uint8)
+
+    def msm_with_cached_scalars(self, coeffs_desc, bases):
+        return self.msm(coeffs_desc, bases)
+
+    def msm_with_cached_base(self, coeffs, base_desc):
+        return self.msm(coeffs, base_desc)
+
+    def msm_with_cached_inputs(self, coeffs_desc, base_desc):
+        return self.msm(coeffs_desc, base_desc)

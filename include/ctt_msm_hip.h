@@ -1,0 +1,152 @@
+/* ctt_msm_hip.h -- C ABI of libctt_msm_hip.so, the MI355X (gfx950) multi-scalar-multiplication engine.
+ *
+ * Part 1 re-declares, with identical names, argument order and struct layouts, the MSM symbols of the
+ * reference's generated C API, so the library can be linked in place of libconstantine for this path:
+ *
+ *   serial   : bindings/c_curve_decls.nim:418-431           -> include/constantine/curves/bls12_381.h:163-164,184-185,212-213,233-234
+ *                                                               include/constantine/curves/bn254_snarks.h:163-164,184-185,212-213,233-234
+ *                                                               include/constantine/curves/pallas.h:125-126,146-147
+ *                                                               include/constantine/curves/vesta.h:125-126,146-147
+ *   parallel : bindings/c_curve_decls_parallel.nim:33-45    -> include/constantine/curves/{bls12_381,bn254_snarks,pallas,vesta}_parallel.h:20-23
+ *
+ * All pointers are HOST pointers, buffers are caller-owned, `r` is out-only, the functions block until the
+ * result is written, return void and never report an error (same contract as the reference); on a HIP failure
+ * the process aborts with a diagnostic -- there is no CPU fallback.  `tp` is accepted and ignored (the GPU
+ * replaces the thread pool).  len == 0 yields the neutral element (undefined behaviour upstream).
+ * The result is the same group element as the reference's; its (X,Y,Z) representative is the canonical one
+ * with Z = 1 (neutral: jac (1,1,0), prj (0,1,0)).
+ *
+ * Part 2 is the device-resident interface (inputs already in HBM): the hook for Halo2-ZAL style cached bases
+ * (constantine-rust/constantine-halo2-zal/src/lib.rs:60-95) and what bench.py times.
+ */
+#ifndef CTT_MSM_HIP_H
+#define CTT_MSM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- types: layout-compatible with include/constantine/core/datatypes.h:42-50, curves/bigints.h:18-21,
+ *      curves/bls12_381.h:19-27, bn254_snarks.h:19-27, pallas.h:19-24, vesta.h:19-24 ---------------------- */
+#ifndef CTT_MSM_HIP_NO_TYPES
+typedef size_t secret_word;
+#define CTT_WORD_BITWIDTH (sizeof(secret_word) * 8)
+#define CTT_WORDS_REQUIRED(bits) (((bits) + CTT_WORD_BITWIDTH - 1) / CTT_WORD_BITWIDTH)
+
+typedef struct ctt_threadpool ctt_threadpool; /* opaque, core/threadpool.h:21 */
+
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(255)]; } big255;
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(254)]; } big254;
+
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(255)]; } bls12_381_fr;
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(381)]; } bls12_381_fp;
+typedef struct { bls12_381_fp c[2]; } bls12_381_fp2;
+typedef struct { bls12_381_fp x, y; } bls12_381_g1_aff;
+typedef struct { bls12_381_fp x, y, z; } bls12_381_g1_jac;
+typedef struct { bls12_381_fp x, y, z; } bls12_381_g1_prj;
+typedef struct { bls12_381_fp2 x, y; } bls12_381_g2_aff;
+typedef struct { bls12_381_fp2 x, y, z; } bls12_381_g2_jac;
+typedef struct { bls12_381_fp2 x, y, z; } bls12_381_g2_prj;
+
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(254)]; } bn254_snarks_fr;
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(254)]; } bn254_snarks_fp;
+typedef struct { bn254_snarks_fp c[2]; } bn254_snarks_fp2;
+typedef struct { bn254_snarks_fp x, y; } bn254_snarks_g1_aff;
+typedef struct { bn254_snarks_fp x, y, z; } bn254_snarks_g1_jac;
+typedef struct { bn254_snarks_fp x, y, z; } bn254_snarks_g1_prj;
+typedef struct { bn254_snarks_fp2 x, y; } bn254_snarks_g2_aff;
+typedef struct { bn254_snarks_fp2 x, y, z; } bn254_snarks_g2_jac;
+typedef struct { bn254_snarks_fp2 x, y, z; } bn254_snarks_g2_prj;
+
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(255)]; } pallas_fr;
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(255)]; } pallas_fp;
+typedef struct { pallas_fp x, y; } pallas_ec_aff;
+typedef struct { pallas_fp x, y, z; } pallas_ec_jac;
+typedef struct { pallas_fp x, y, z; } pallas_ec_prj;
+
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(255)]; } vesta_fr;
+typedef struct { secret_word limbs[CTT_WORDS_REQUIRED(255)]; } vesta_fp;
+typedef struct { vesta_fp x, y; } vesta_ec_aff;
+typedef struct { vesta_fp x, y, z; } vesta_ec_jac;
+typedef struct { vesta_fp x, y, z; } vesta_ec_prj;
+#endif /* CTT_MSM_HIP_NO_TYPES */
+
+/* ---- Part 1: Constantine-compatible MSM symbols -------------------------------------------------------- */
+#define CTT_MSM_DECL_SERIAL(EC, AFF, BIG, FR)                                                                      \
+  void ctt_##EC##_multi_scalar_mul_big_coefs_vartime(EC* r, const BIG coefs[], const AFF points[], size_t len);    \
+  void ctt_##EC##_multi_scalar_mul_fr_coefs_vartime(EC* r, const FR coefs[], const AFF points[], size_t len);
+#define CTT_MSM_DECL_PARALLEL(EC, AFF, BIG, FR)                                                                    \
+  void ctt_##EC##_multi_scalar_mul_big_coefs_vartime_parallel(const ctt_threadpool* tp, EC* r, const BIG coefs[],  \
+                                                              const AFF points[], size_t len);                     \
+  void ctt_##EC##_multi_scalar_mul_fr_coefs_vartime_parallel(const ctt_threadpool* tp, EC* r, const FR coefs[],    \
+                                                             const AFF points[], size_t len);
+
+/* bls12_381.h:163-164,184-185 ; bls12_381_parallel.h:20-23 */
+CTT_MSM_DECL_SERIAL(bls12_381_g1_jac, bls12_381_g1_aff, big255, bls12_381_fr)
+CTT_MSM_DECL_SERIAL(bls12_381_g1_prj, bls12_381_g1_aff, big255, bls12_381_fr)
+CTT_MSM_DECL_PARALLEL(bls12_381_g1_jac, bls12_381_g1_aff, big255, bls12_381_fr)
+CTT_MSM_DECL_PARALLEL(bls12_381_g1_prj, bls12_381_g1_aff, big255, bls12_381_fr)
+/* bls12_381.h:212-213,233-234 (G2 has no parallel variant upstream) */
+CTT_MSM_DECL_SERIAL(bls12_381_g2_jac, bls12_381_g2_aff, big255, bls12_381_fr)
+CTT_MSM_DECL_SERIAL(bls12_381_g2_prj, bls12_381_g2_aff, big255, bls12_381_fr)
+/* bn254_snarks.h:163-164,184-185,212-213,233-234 ; bn254_snarks_parallel.h:20-23
+ * ctt_bn254_snarks_g1_prj_multi_scalar_mul_fr_coefs_vartime_parallel is the Halo2-ZAL entry
+ * (constantine-rust/constantine-halo2-zal/src/lib.rs:42-58). */
+CTT_MSM_DECL_SERIAL(bn254_snarks_g1_jac, bn254_snarks_g1_aff, big254, bn254_snarks_fr)
+CTT_MSM_DECL_SERIAL(bn254_snarks_g1_prj, bn254_snarks_g1_aff, big254, bn254_snarks_fr)
+CTT_MSM_DECL_PARALLEL(bn254_snarks_g1_jac, bn254_snarks_g1_aff, big254, bn254_snarks_fr)
+CTT_MSM_DECL_PARALLEL(bn254_snarks_g1_prj, bn254_snarks_g1_aff, big254, bn254_snarks_fr)
+CTT_MSM_DECL_SERIAL(bn254_snarks_g2_jac, bn254_snarks_g2_aff, big254, bn254_snarks_fr)
+CTT_MSM_DECL_SERIAL(bn254_snarks_g2_prj, bn254_snarks_g2_aff, big254, bn254_snarks_fr)
+/* pallas.h:125-126,146-147 ; pallas_parallel.h:20-23 */
+CTT_MSM_DECL_SERIAL(pallas_ec_jac, pallas_ec_aff, big255, pallas_fr)
+CTT_MSM_DECL_SERIAL(pallas_ec_prj, pallas_ec_aff, big255, pallas_fr)
+CTT_MSM_DECL_PARALLEL(pallas_ec_jac, pallas_ec_aff, big255, pallas_fr)
+CTT_MSM_DECL_PARALLEL(pallas_ec_prj, pallas_ec_aff, big255, pallas_fr)
+/* vesta.h:125-126,146-147 ; vesta_parallel.h:20-23 */
+CTT_MSM_DECL_SERIAL(vesta_ec_jac, vesta_ec_aff, big255, vesta_fr)
+CTT_MSM_DECL_SERIAL(vesta_ec_prj, vesta_ec_aff, big255, vesta_fr)
+CTT_MSM_DECL_PARALLEL(vesta_ec_jac, vesta_ec_aff, big255, vesta_fr)
+CTT_MSM_DECL_PARALLEL(vesta_ec_prj, vesta_ec_aff, big255, vesta_fr)
+
+/* ---- Part 2: device-resident interface ------------------------------------------------------------------ */
+typedef struct ctt_hip_msm_ctx ctt_hip_msm_ctx;
+
+enum { CTT_HIP_BLS12_381_G1 = 0, CTT_HIP_BLS12_381_G2 = 1, CTT_HIP_BN254_SNARKS_G1 = 2,
+       CTT_HIP_BN254_SNARKS_G2 = 3, CTT_HIP_PALLAS = 4, CTT_HIP_VESTA = 5 };
+enum { CTT_HIP_COEF_BIG = 0, CTT_HIP_COEF_FR = 1 };
+enum { CTT_HIP_OUT_AFF = 0, CTT_HIP_OUT_JAC = 1, CTT_HIP_OUT_PRJ = 2 };
+
+int ctt_hip_msm_abi_version(void);
+/* One context = one GPU, one stream, one grow-only workspace. NULL ctx in the calls below = process default
+ * context on device $CTT_HIP_DEVICE (default 0). */
+ctt_hip_msm_ctx* ctt_hip_msm_ctx_create(int device);
+void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
+/* key in {"c","K","rs_log","S"}; value 0 = automatic. Returns 0, or -1 for an unknown key. */
+int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
+/* r (HOST memory, `out_kind` layout) = sum coefs[i] * points[i]; d_coefs / d_points are DEVICE pointers
+ * (BigInt canonical or Fr Montgomery 32-byte scalars; affine Montgomery points, C-API struct layout).
+ * Returns 0, or -1 for a bad curve id.  Blocks until r is written. */
+int ctt_hip_msm_device(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, int out_kind, void* r, const void* d_coefs,
+                       const void* d_points, size_t len);
+/* HIP-event stage times (ms) of the last call: digits, sort, accumulate, merge, reduce, total. */
+int ctt_hip_msm_last_timings(ctt_hip_msm_ctx* ctx, float* ms, int cap);
+/* plan of the last call: c, W, K, G, S, resident lanes */
+int ctt_hip_msm_last_plan(ctt_hip_msm_ctx* ctx, int* out, int cap);
+/* d_out[i] = [s_i]G, deterministic synthetic subgroup points (bench / test inputs) */
+int ctt_hip_gen_points(ctt_hip_msm_ctx* ctx, int curve, uint64_t seed, uint64_t first, uint32_t n, void* d_out);
+/* element-wise coordinate-field op on device arrays (0 mul, 1 sqr, 2 add, 3 sub, 4 neg): kernel unit tests */
+int ctt_hip_field_op(ctt_hip_msm_ctx* ctx, int curve, int op, const void* d_a, const void* d_b, void* d_r, uint32_t n);
+/* host-only: r (`out_kind` layout) = sum of n affine points -- combines the per-GPU partial results of a
+ * sharded MSM (the `r ~+= partial` of ec_multi_scalar_mul_parallel.nim:427-429). Needs no GPU. */
+int ctt_hip_ec_sum_affine(int curve, int out_kind, void* r, const void* pts_aff, size_t n);
+/* the engine's hipStream_t */
+void* ctt_hip_msm_stream(ctt_hip_msm_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTT_MSM_HIP_H */

@@ -1,0 +1,70 @@
+"""world_size-2 gloo test of the point-sharded MSM (constantine_amd/parallel.py) on CPU.
+The per-rank partial MSM is computed by the oracle here (no GPU in this container); the sharding, the
+all_gather exchange and the host-side combine (product code, ctt_hip_ec_sum_affine) are the parts under test."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, n, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from constantine_amd import parallel
+    from oracle import cref
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bits = 254 if "bn254" in name else 255
+        start, ln = parallel.shard_bounds(n, world, rank)
+        pts = cref.gen_points(name, 77, ln, first=start, nthreads=1)
+        sc = cref.synth_scalars(78, ln, bits, first=start)
+        res = parallel.msm_sharded(name, lambda: cref.msm(name, sc, pts)[0])
+        q.put((rank, bytes(res)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,n", [("bls12_381_g1", 101), ("bn254_snarks_g1", 64)])
+def test_sharded_msm_two_ranks(name, n):
+    from oracle import cref
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bits = 254 if "bn254" in name else 255
+    pts = cref.gen_points(name, 77, n)
+    sc = cref.synth_scalars(78, n, bits)
+    expect, _ = cref.msm(name, sc, pts)
+    assert out[0] == out[1] == bytes(expect)
+
+
+def test_shard_bounds_balanced():
+    from constantine_amd.parallel import shard_bounds
+    for n, w in ((40, 12), (7, 8), (1 << 24, 8), (5, 2)):
+        spans = [shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and sum(l for _, l in spans) == n
+        for (s0, l0), (s1, _) in zip(spans, spans[1:]):
+            assert s0 + l0 == s1
+        ls = [l for _, l in spans]
+        assert max(ls) - min(ls) <= 1

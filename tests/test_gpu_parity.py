@@ -1,0 +1,311 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI
+(include/ctt_msm_hip.h), against the CPU oracle on the same inputs -- byte-exact on the canonical affine
+image (the reference compares group elements, never raw (X,Y,Z): tests/math_elliptic_curves/t_ec_template.nim:1440-1483).
+
+Nothing here reads /root/reference; golden vectors come from tests/golden/.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pyoracle as po
+from tests import _golden
+
+pytestmark = pytest.mark.gpu
+
+ALL = list(po.CURVES)
+G1S = ["bls12_381_g1", "bn254_snarks_g1", "pallas", "vesta"]
+NT = max(1, (os.cpu_count() or 1))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def dev(torch_cuda):
+    from constantine_amd import DeviceMsm
+    d = DeviceMsm(0)
+    yield d
+    d.close()
+
+
+def _aff(curve, b):
+    return curve.aff_from_bytes(bytes(b))
+
+
+def _decode(curve, coord, r):
+    return {"jac": curve.jac_from_bytes, "prj": curve.prj_from_bytes, "aff": curve.aff_from_bytes}[coord](bytes(r))
+
+
+def _to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ----------------------------------------------------------------------------------------------
+# kernels below the MSM: Montgomery arithmetic and the input generator
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ALL)
+def test_field_ops_on_device(name, dev, torch_cuda):
+    torch = torch_cuda
+    curve = po.CURVES[name]
+    F = curve.F
+    base = F if F.degree == 1 else F.base
+    p = base.p
+    rng = random.Random(11)
+    n = 2048
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 1 << (p.bit_length() - 1), base.R % p, (base.R * base.R) % p]
+
+    def rnd():
+        v = rng.choice(edge) if rng.random() < 0.15 else rng.randrange(p)
+        if F.degree == 1:
+            return v
+        return (v, rng.choice(edge) if rng.random() < 0.15 else rng.randrange(p))
+
+    A = [rnd() for _ in range(n)]
+    B = [rnd() for _ in range(n)]
+    a = np.frombuffer(b"".join(F.to_mont_bytes(x) for x in A), dtype=np.uint8).reshape(n, -1)
+    b = np.frombuffer(b"".join(F.to_mont_bytes(x) for x in B), dtype=np.uint8).reshape(n, -1)
+    da, db = _to_dev(torch, a), _to_dev(torch, b)
+    dr = torch.empty_like(da)
+    ops = {0: F.mul, 1: lambda x, y: F.sqr(x), 2: F.add, 3: F.sub, 4: lambda x, y: F.neg(x)}
+    for op, fn in ops.items():
+        dev.field_op(name, op, da, db, dr, n)
+        out = dr.cpu().numpy()
+        for i in range(n):
+            assert F.from_mont_bytes(bytes(out[i])) == fn(A[i], B[i]), (name, op, i)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_gen_points_matches_oracle(name, dev, torch_cuda):
+    torch = torch_cuda
+    info_bytes = cref.AFF_BYTES[name]
+    n = 300 if po.CURVES[name].F.degree == 1 else 64
+    d = torch.empty((n, info_bytes), dtype=torch.uint8, device="cuda")
+    dev.gen_points(name, 4242, n, d, first=17)
+    expect = cref.gen_points(name, 4242, n, first=17)
+    assert bytes(d.cpu().numpy().tobytes()) == bytes(expect.tobytes())
+
+
+# ----------------------------------------------------------------------------------------------
+# MSM through the Constantine-compatible C symbols (host pointers)
+# ----------------------------------------------------------------------------------------------
+SIZES = [1, 2, 3, 4, 5, 6, 7, 8, 16, 32, 64, 128, 1024, 2048, 16384]  # t_ec_template.nim:1459-1483, parallel template :170-192
+
+
+@pytest.mark.parametrize("name", G1S)
+@pytest.mark.parametrize("n", SIZES)
+def test_msm_host_symbols_vs_oracle(name, n):
+    from constantine_amd import multiScalarMul_vartime, multiScalarMul_vartime_parallel
+    curve = po.CURVES[name]
+    pts = cref.gen_points(name, 100 + n, n)
+    sc = cref.synth_scalars(200 + n, n, curve.scalar_bits)   # uniform < 2^bits, NOT reduced mod r
+    expect, _ = cref.msm(name, sc, pts, nthreads=NT)
+    expect = _aff(curve, expect)
+    assert _decode(curve, "jac", multiScalarMul_vartime(name, sc, pts, coord="jac")) == expect
+    assert _decode(curve, "prj", multiScalarMul_vartime_parallel(None, name, sc, pts, coord="prj")) == expect
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g2", "bn254_snarks_g2"])
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 1024])
+def test_msm_g2_vs_oracle(name, n):
+    from constantine_amd import multiScalarMul_vartime
+    curve = po.CURVES[name]
+    pts = cref.gen_points(name, 300 + n, n)
+    sc = cref.synth_scalars(400 + n, n, curve.scalar_bits)
+    expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
+    assert _decode(curve, "jac", multiScalarMul_vartime(name, sc, pts, coord="jac")) == expect
+    assert _decode(curve, "prj", multiScalarMul_vartime(name, sc, pts, coord="prj")) == expect
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_snarks_g1", "pallas", "vesta", "bls12_381_g2"])
+def test_fr_coefs_symbols(name):
+    from constantine_amd import multiScalarMul_vartime
+    curve = po.CURVES[name]
+    n = 500 if curve.F.degree == 1 else 40
+    pts = cref.gen_points(name, 61, n)
+    ks = [po.synth_scalar(62, i, 256) % curve.Fr.p for i in range(n)]
+    can = curve.scalars_to_array(ks)
+    mont = curve.fr_scalars_to_array(ks)
+    expect = _aff(curve, cref.msm(name, can, pts, nthreads=NT)[0])
+    assert _decode(curve, "jac", multiScalarMul_vartime(name, mont, pts, coord="jac", fr_coefs=True)) == expect
+
+
+def test_halo2_zal_engine_entry():
+    """CttEngine.msm -> ctt_bn254_snarks_g1_prj_multi_scalar_mul_fr_coefs_vartime_parallel (lib.rs:42-58);
+    sizes 2^3..2^14 like t_zal_msm_accel.rs:28-69."""
+    from constantine_amd import CttEngine
+    name = "bn254_snarks_g1"
+    curve = po.CURVES[name]
+    eng = CttEngine(0)
+    for k in (3, 8, 14):
+        n = 1 << k
+        pts = cref.gen_points(name, 70 + k, n)
+        ks = [po.synth_scalar(71 + k, i, 256) % curve.Fr.p for i in range(n)]
+        can, mont = curve.scalars_to_array(ks), curve.fr_scalars_to_array(ks)
+        expect = _aff(curve, cref.msm(name, can, pts, nthreads=NT)[0])
+        assert curve.prj_from_bytes(bytes(eng.msm(mont, pts))) == expect
+        assert curve.prj_from_bytes(bytes(eng.msm_with_cached_base(mont, eng.get_base_descriptor(pts)))) == expect
+
+
+@pytest.mark.parametrize("group,cname", [("g1", "bls12_381_g1"), ("g2", "bls12_381_g2")])
+def test_eip2537_golden_vectors(group, cname):
+    from constantine_amd import multiScalarMul_vartime
+    curve = po.CURVES[cname]
+    for name, scalars, points, expected in _golden.eip2537(group):
+        sc = curve.scalars_to_array([k % curve.order for k in scalars])
+        pts = curve.points_to_array(points)
+        assert _decode(curve, "jac", multiScalarMul_vartime(cname, sc, pts, coord="jac")) == expected, name
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_snarks_g1", "pallas", "vesta"])
+def test_scalar_mul_kat_sum(name):
+    """MSM(k_i, P_i) over the reference's 40 full-width [k]P=Q vectors == sum Q_i."""
+    from constantine_amd import multiScalarMul_vartime
+    curve = po.CURVES[name]
+    kats = _golden.scalar_mul_kats(name)[-40:]
+    expect = None
+    for _, _, Q in kats:
+        expect = curve.add(expect, Q)
+    sc = curve.scalars_to_array([k for _, k, _ in kats])
+    pts = curve.points_to_array([P for P, _, _ in kats])
+    assert _decode(curve, "jac", multiScalarMul_vartime(name, sc, pts)) == expect
+
+
+# ----------------------------------------------------------------------------------------------
+# edge cases
+# ----------------------------------------------------------------------------------------------
+def test_edge_cases_infinity_cancellation_empty():
+    from constantine_amd import multiScalarMul_vartime
+    name = "bls12_381_g1"
+    curve = po.CURVES[name]
+    G = curve.gen
+    pts = curve.points_to_array([G, None, G, curve.neg(G), G, None])
+    sc = curve.scalars_to_array([5, 77, 5, 3, 0, 0])
+    assert _decode(curve, "jac", multiScalarMul_vartime(name, sc, pts)) == curve.scalar_mul(7, G)
+    pts = curve.points_to_array([G, curve.neg(G)])
+    sc = curve.scalars_to_array([9, 9])
+    r = multiScalarMul_vartime(name, sc, pts, coord="jac")
+    assert curve.jac_from_bytes(bytes(r)) is None
+    one = curve.F.to_mont_bytes(1)
+    assert bytes(r) == one + one + bytes(48)           # EC_ShortW_Jac neutral (1,1,0)
+    r = multiScalarMul_vartime(name, sc, pts, coord="prj")
+    assert bytes(r) == bytes(48) + one + bytes(48)     # EC_ShortW_Prj neutral (0,1,0)
+    r = multiScalarMul_vartime(name, np.zeros((0, 32), np.uint8), np.zeros((0, 96), np.uint8))
+    assert curve.jac_from_bytes(bytes(r)) is None      # len == 0 -> neutral
+    r = multiScalarMul_vartime(name, curve.scalars_to_array([0, 0, 0]), curve.points_to_array([G, G, G]))
+    assert curve.jac_from_bytes(bytes(r)) is None
+
+
+def test_all_equal_scalars_one_bucket_per_window():
+    """Adversarial distribution: every pair lands in the same bucket -> long head/tail chains + merge tree."""
+    from constantine_amd import multiScalarMul_vartime
+    name = "bls12_381_g1"
+    curve = po.CURVES[name]
+    n = 20000
+    pts = cref.gen_points(name, 41, n)
+    sc = np.tile(cref.synth_scalars(42, 1, 255), (n, 1))
+    expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
+    assert _decode(curve, "jac", multiScalarMul_vartime(name, sc, pts)) == expect
+
+
+def test_all_equal_points_bug366_style():
+    """t_ec_shortw_jac_g2_msm_bug_366.nim: N = 22529, all points equal (P == Q additions everywhere)."""
+    from constantine_amd import multiScalarMul_vartime
+    for name, n in (("bn254_snarks_g1", 22529), ("bn254_snarks_g2", 2049)):
+        curve = po.CURVES[name]
+        pts = np.tile(cref.gen_points(name, 51, 1), (n, 1))
+        sc = cref.synth_scalars(52, n, curve.scalar_bits)
+        expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
+        assert _decode(curve, "jac", multiScalarMul_vartime(name, sc, pts)) == expect
+        sc2 = np.tile(sc[:1], (n, 1))
+        expect = _aff(curve, cref.msm(name, sc2, pts, nthreads=NT)[0])
+        assert _decode(curve, "jac", multiScalarMul_vartime(name, sc2, pts)) == expect
+
+
+def test_window_sizes_and_lane_spans(dev, torch_cuda):
+    """Same answer for every plan: window bits (incl. divisors of the scalar width), entries per lane, reduce chunk."""
+    torch = torch_cuda
+    name = "bls12_381_g1"
+    curve = po.CURVES[name]
+    n = 5000
+    pts = cref.gen_points(name, 91, n)
+    sc = cref.synth_scalars(92, n, 255)
+    sc[:50, 24:31] = 0xFF
+    sc[:50, 31] |= 0x7F
+    expect = bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
+    dp, ds = _to_dev(torch, pts), _to_dev(torch, sc)
+    try:
+        for c, K, rs in ((3, 4, 1), (5, 8, 2), (8, 16, 3), (13, 0, 3), (15, 12, 4), (16, 0, 3), (0, 0, 0)):
+            dev.set_option("c", c)
+            dev.set_option("K", K)
+            dev.set_option("rs_log", rs)
+            assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (c, K, rs, dev.last_plan())
+    finally:
+        dev.set_option("c", 0)
+        dev.set_option("K", 0)
+        dev.set_option("rs_log", 0)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json sizes
+# ----------------------------------------------------------------------------------------------
+def _full_size(name, lg, dev, torch, check_oracle):
+    from constantine_amd.msm import ec_sum_affine
+    curve = po.CURVES[name]
+    n = 1 << lg
+    info_bytes = cref.AFF_BYTES[name]
+    dp = torch.empty((n, info_bytes), dtype=torch.uint8, device="cuda")
+    dev.gen_points(name, 1000 + lg, n, dp)
+    sc = cref.synth_scalars(2000 + lg, n, curve.scalar_bits)
+    ds = _to_dev(torch, sc)
+    full = dev.msm(name, ds, dp, n, coord="aff")
+    # size-independent property 1: the sum of the two half-MSMs is the whole MSM
+    h = n // 2
+    a = dev.msm(name, ds[:h], dp[:h], h, coord="aff")
+    b = dev.msm(name, ds[h:], dp[h:], n - h, coord="aff")
+    assert bytes(ec_sum_affine(name, np.stack([a, b]))) == bytes(full)
+    # property 2: a different plan (window size, lane span) gives the same element
+    dev.set_option("c", 13)
+    dev.set_option("K", 36)
+    try:
+        assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == bytes(full)
+    finally:
+        dev.set_option("c", 0)
+        dev.set_option("K", 0)
+    if check_oracle:
+        expect, _ = cref.msm(name, sc, dp.cpu().numpy(), nthreads=NT)
+        assert bytes(expect) == bytes(full)
+
+
+def test_bls12_381_g1_2pow20(dev, torch_cuda):
+    """BASELINE config 2: BLS12-381 G1, 2^20 pairs, bit-exact vs the CPU path."""
+    _full_size("bls12_381_g1", 20, dev, torch_cuda, check_oracle=True)
+
+
+def test_bn254_g1_2pow22_properties(dev, torch_cuda):
+    """BASELINE config 3 size (2^22); oracle comparison on the first 2^18 pairs."""
+    torch = torch_cuda
+    name = "bn254_snarks_g1"
+    _full_size(name, 22, dev, torch, check_oracle=False)
+    n = 1 << 18
+    dp = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    dev.gen_points(name, 555, n, dp)
+    ks = [po.synth_scalar(556, i, 256) % po.CURVES[name].Fr.p for i in range(2048)]
+    sc = cref.synth_scalars(557, n, 254)
+    expect, _ = cref.msm(name, sc, dp.cpu().numpy(), nthreads=NT)
+    assert bytes(dev.msm(name, _to_dev(torch, sc), dp, n, coord="aff")) == bytes(expect)
+
+
+def test_pasta_and_g2_2pow20_properties(dev, torch_cuda):
+    """BASELINE config 5 sizes: properties at 2^20 (Pallas, Vesta) and 2^18 (BLS12-381 G2), oracle on a prefix."""
+    _full_size("pallas", 20, dev, torch_cuda, check_oracle=False)
+    _full_size("vesta", 20, dev, torch_cuda, check_oracle=False)
+    _full_size("bls12_381_g2", 18, dev, torch_cuda, check_oracle=False)
