@@ -47,8 +47,9 @@ __global__ void __launch_bounds__(EC_BLOCK) k_merge_final(MergeArgs<F> a) {
   merge_final_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
 }
 template <class F>
-__global__ void __launch_bounds__(EC_BLOCK) k_reduce(ReduceArgs<F> a) {
-  reduce_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+__global__ void __launch_bounds__(EC_BLOCK) k_pyr(PyrArgs<F> a, uint32_t ntasks) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ntasks) pyr_body<F>(a, blockIdx.y, t);
 }
 template <class C>
 __global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t first, uint32_t n, Affine<typename C::F>* out) {
@@ -96,6 +97,21 @@ struct HipBackend {
   void d2h(void* dst, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  // small device->host word, overlapped with kernels launched after it
+  uint32_t* h_word = nullptr;
+  hipEvent_t ev_word = nullptr;
+  void fetch_u32_async(const uint32_t* d) {
+    if (!h_word) {
+      HIP_CHECK(hipHostMalloc((void**)&h_word, 64, hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&ev_word, hipEventDisableTiming));
+    }
+    HIP_CHECK(hipMemcpyAsync(h_word, d, 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipEventRecord(ev_word, stream));
+  }
+  uint32_t fetch_u32_wait() {
+    HIP_CHECK(hipEventSynchronize(ev_word));
+    return *h_word;
   }
   void stage_begin(int s) {
     HIP_CHECK(hipEventRecord(ev_begin[s], stream));
@@ -150,8 +166,8 @@ struct HipBackend {
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
-  void launch_reduce(const ReduceArgs<F>& a, uint32_t W) {
-    hipLaunchKernelGGL(k_reduce<F>, grid2(a.n_out, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
+  void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
+    hipLaunchKernelGGL(k_pyr<F>, grid2(ntasks, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, ntasks);
     HIP_CHECK(hipGetLastError());
   }
 };
@@ -191,10 +207,10 @@ struct CurveImpl {
     uint32_t lanes = e.opt.lanes;
     e.opt = *opt;
     e.opt.lanes = lanes;
-    XYZZ<F> res = e.run((const uint32_t*)d_coefs, coef_is_fr != 0, (const Affine<F>*)d_points, n);
+    auto res = e.run((const uint32_t*)d_coefs, coef_is_fr != 0, (const Affine<F>*)d_points, n);
     const MsmPlan& p = e.last_plan;
     plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
-    write_result<F>(r_host, res, out_kind);
+    write_result<typename Engine::HF>(r_host, res, out_kind);
   }
   static void gen_points(HipBackend* bk, uint64_t seed, uint64_t first, uint32_t n, void* d_out) {
     hipLaunchKernelGGL(k_gen_points<C>, dim3((n + EC_BLOCK - 1) / EC_BLOCK), dim3(EC_BLOCK), 0, bk->stream, seed, first, n,
@@ -209,10 +225,11 @@ struct CurveImpl {
     HIP_CHECK(hipStreamSynchronize(bk->stream));
   }
   static void ec_sum_affine(const void* pts_aff, size_t n, void* r_host, int out_kind) {
-    const Affine<F>* p = (const Affine<F>*)pts_aff;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (size_t i = 0; i < n; i++) xyzz_madd<F>(acc, p[i], false);
-    write_result<F>(r_host, acc, out_kind);
+    using HF = typename Engine::HF;
+    const Affine<HF>* p = (const Affine<HF>*)pts_aff;
+    XYZZ<HF> acc = XYZZ<HF>::inf();
+    for (size_t i = 0; i < n; i++) xyzz_madd<HF>(acc, p[i], false);
+    write_result<HF>(r_host, acc, out_kind);
   }
   static const CurveOps* ops() {
     static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, run, gen_points, field_op, ec_sum_affine};

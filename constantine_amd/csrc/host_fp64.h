@@ -1,0 +1,134 @@
+// host_fp64.h -- host-only prime field on 64-bit limbs (unsigned __int128 products).
+//
+// Same static interface and the same in-memory representation as ctt::Fp<PP> (Montgomery residue,
+// little-endian limbs), so XYZZ<Fp64<PP>> can be laid over the bytes the device returns.  Used for the
+// final Horner over (window, bit) and the affine normalisation of the result -- the only EC arithmetic
+// the engine does on the CPU (about 2*W*c group operations per MSM, the serial tail the reference runs
+// at ec_multi_scalar_mul.nim:250-254).
+#pragma once
+#include "fp.h"
+
+namespace ctt {
+
+template <class PP>
+struct Fp64 {
+  using Params = PP;
+  static constexpr int N = PP::N / 2;
+  static constexpr int NBYTES = 8 * N;
+  typedef unsigned __int128 u128;
+  uint64_t l[N];
+
+  static inline uint64_t P(int i) { return (uint64_t)PP::P[2 * i] | ((uint64_t)PP::P[2 * i + 1] << 32); }
+  static inline uint64_t m0inv() {
+    // -p^-1 mod 2^64 from the 32-bit constant by one Newton step
+    uint64_t p0 = P(0);
+    uint64_t inv = (uint64_t)(0u - PP::M0INV);  // p^-1 mod 2^32
+    inv *= 2 - p0 * inv;                        // mod 2^64
+    return (uint64_t)0 - inv;
+  }
+
+  static inline Fp64 zero() { Fp64 r; for (int i = 0; i < N; i++) r.l[i] = 0; return r; }
+  static inline Fp64 one() {
+    Fp64 r;
+    for (int i = 0; i < N; i++) r.l[i] = (uint64_t)PP::ONE[2 * i] | ((uint64_t)PP::ONE[2 * i + 1] << 32);
+    return r;
+  }
+  inline bool is_zero() const { uint64_t a = 0; for (int i = 0; i < N; i++) a |= l[i]; return a == 0; }
+  static inline bool eq(const Fp64& a, const Fp64& b) { uint64_t d = 0; for (int i = 0; i < N; i++) d |= a.l[i] ^ b.l[i]; return d == 0; }
+  static inline Fp64 select(bool c, const Fp64& a, const Fp64& b) { return c ? a : b; }
+
+  static inline Fp64 reduce_once(const uint64_t* t, uint64_t top) {
+    uint64_t d[N];
+    uint64_t bw = 0;
+    for (int i = 0; i < N; i++) {
+      u128 x = (u128)t[i] - P(i) - bw;
+      d[i] = (uint64_t)x;
+      bw = (uint64_t)(x >> 64) & 1;
+    }
+    Fp64 r;
+    const bool ge = (bw == 0) | (top != 0);
+    for (int i = 0; i < N; i++) r.l[i] = ge ? d[i] : t[i];
+    return r;
+  }
+  static inline Fp64 add(const Fp64& a, const Fp64& b) {
+    uint64_t t[N];
+    uint64_t c = 0;
+    for (int i = 0; i < N; i++) {
+      u128 s = (u128)a.l[i] + b.l[i] + c;
+      t[i] = (uint64_t)s;
+      c = (uint64_t)(s >> 64);
+    }
+    return reduce_once(t, c);
+  }
+  static inline Fp64 dbl(const Fp64& a) { return add(a, a); }
+  static inline Fp64 sub(const Fp64& a, const Fp64& b) {
+    uint64_t t[N];
+    uint64_t bw = 0;
+    for (int i = 0; i < N; i++) {
+      u128 x = (u128)a.l[i] - b.l[i] - bw;
+      t[i] = (uint64_t)x;
+      bw = (uint64_t)(x >> 64) & 1;
+    }
+    Fp64 r;
+    const uint64_t mask = (uint64_t)0 - bw;
+    uint64_t c = 0;
+    for (int i = 0; i < N; i++) {
+      u128 s = (u128)t[i] + (P(i) & mask) + c;
+      r.l[i] = (uint64_t)s;
+      c = (uint64_t)(s >> 64);
+    }
+    return r;
+  }
+  static inline Fp64 neg(const Fp64& a) { return a.is_zero() ? a : sub(zero(), a); }
+  static inline Fp64 cneg(const Fp64& a, bool c) { return c ? neg(a) : a; }
+
+  // product-scanning Montgomery multiplication with a 192-bit column accumulator
+  static inline Fp64 mul(const Fp64& a, const Fp64& b) {
+    uint64_t p[N];
+    for (int i = 0; i < N; i++) p[i] = P(i);
+    const uint64_t mi = m0inv();
+    uint64_t m[N], t[N];
+    u128 acc = 0;     // low 128 bits
+    uint64_t hi = 0;  // bits 128..191
+    auto mac = [&](uint64_t x, uint64_t y) {
+      u128 pr = (u128)x * y;
+      acc += pr;
+      hi += (acc < pr) ? 1 : 0;
+    };
+    auto shift = [&]() {
+      acc = (acc >> 64) | ((u128)hi << 64);
+      hi = 0;
+    };
+    for (int k = 0; k < N; k++) {
+      for (int i = 0; i <= k; i++) mac(a.l[i], b.l[k - i]);
+      for (int i = 0; i < k; i++) mac(m[i], p[k - i]);
+      m[k] = (uint64_t)acc * mi;
+      mac(m[k], p[0]);
+      shift();
+    }
+    for (int k = N; k < 2 * N; k++) {
+      for (int i = k - N + 1; i < N; i++) mac(a.l[i], b.l[k - i]);
+      for (int i = k - N + 1; i < N; i++) mac(m[i], p[k - i]);
+      t[k - N] = (uint64_t)acc;
+      shift();
+    }
+    return reduce_once(t, (uint64_t)acc);
+  }
+  static inline Fp64 sqr(const Fp64& a) { return mul(a, a); }
+
+  static inline Fp64 inv(const Fp64& a) {  // a^(p-2)
+    Fp64 r = one();
+    for (int i = 64 * N - 1; i >= 0; i--) {
+      r = sqr(r);
+      if ((PP::PM2[i >> 5] >> (i & 31)) & 1u) r = mul(r, a);
+    }
+    return r;
+  }
+};
+
+// device field type -> host field type with the same memory layout
+template <class F> struct HostField;
+template <class PP> struct HostField<Fp<PP>> { using type = Fp64<PP>; };
+template <class PP> struct HostField<Fp2<Fp<PP>>> { using type = Fp2<Fp64<PP>>; };
+
+}  // namespace ctt

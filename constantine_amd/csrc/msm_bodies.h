@@ -11,9 +11,9 @@
 //            runs fully inside a lane's range go straight to the bucket array, runs that
 //            straddle a lane boundary go to head/tail partial slots
 //   merge    partial slots of one bucket are combined (tree over lanes, log steps)
-//   reduce   sum_k k*B_k per window as a chunked running sum, recursively
-//            (parallel form of bucketReduce, ec_multi_scalar_mul.nim:186-197)
-//   combine  Horner over windows on the host (ec_multi_scalar_mul.nim:250-254)
+//   reduce   sum_k k*B_k per window re-associated by the bits of k: one shared pairwise-sum pyramid,
+//            depth c-1 (log-depth form of bucketReduce, ec_multi_scalar_mul.nim:186-197)
+//   combine  Horner over (window, bit) on the host (ec_multi_scalar_mul.nim:250-254)
 //
 // Bodies are __host__ __device__ so that tests/emu can execute exactly this code on the CPU
 // (logic check without a GPU); the product path runs them only as HIP kernels.
@@ -224,39 +224,110 @@ CTT_HD void merge_final_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Bucket reduction: sum_i (i + wbase) * A[i] + sum_i P[i], one level of the recursion
+// Bucket reduction  sum_b (b+1) * B_b  per window, in log depth.
+//
+// The reference's bucketReduce (ec_multi_scalar_mul.nim:186-197) is a serial running sum: 2*2^(c-1)
+// dependent additions.  On the GPU a dependent chain of EC additions costs ~23 us per link (one lane
+// cannot go faster than one SIMD), so the sum is re-associated by the bits of the bucket index:
+//
+//     sum_b b*B_b = sum_l 2^l * O_l ,   O_l = sum of the buckets whose index has bit l set.
+//
+// All O_l come out of ONE shared pairwise-sum pyramid: level l+1 = pairwise sums of level l (aligned
+// blocks of 2^l buckets), and O_l = sum of the odd-indexed elements of level l.  Total work is 2*2^(c-1)
+// additions (same as the running sum) but the depth is c-1 additions.  Pass p builds pyramid level p+1,
+// starts the odd-element tree of level p and halves the trees of the earlier levels.  The host finishes
+// with one Horner over (window, bit) -- see combine_windows_bits in msm_pipeline.h.
 // ---------------------------------------------------------------------------------------------
 template <class F>
-struct ReduceArgs {
-  const XYZZ<F>* A_in;   // [W][n_in]
-  const XYZZ<F>* P_in;   // [W][n_in] or nullptr
-  XYZZ<F>* A_out;        // [W][n_out]   s * (chunk sum), weight = chunk index at the next level
-  XYZZ<F>* P_out;        // [W][n_out]   locally weighted sum + plain carry-over
-  uint32_t n_in, n_out;
-  uint32_t s, log2s, wbase;
+struct PyrArgs {
+  const XYZZ<F>* buckets;  // [W][B]  pyramid level 0
+  XYZZ<F>* pyr;            // [W][B]  levels >= 1, level l at offset B - (B >> (l-1))
+  XYZZ<F>* q;              // [W][B/2] odd-element trees, tree l at offset B/2 - (B >> (l+1))
+  XYZZ<F>* out;            // [W][c]  O_0 .. O_{c-2}, then TOP = sum of all buckets
+  uint32_t B;
+  int c;
+  int p;                   // pass index, 0 .. c-2
 };
 
 template <class F>
-CTT_HD void reduce_body(const ReduceArgs<F>& a, uint32_t w, uint32_t t) {
-  if (t >= a.n_out) return;
-  const uint64_t base_in = (uint64_t)w * a.n_in;
-  XYZZ<F> acc = XYZZ<F>::inf(), run = XYZZ<F>::inf(), pl = XYZZ<F>::inf();
-  for (int l = (int)a.s - 1; l >= 0; l--) {
-    const uint64_t idx = (uint64_t)t * a.s + (uint32_t)l;
-    if (idx < a.n_in) {
-      XYZZ<F> x = a.A_in[base_in + idx];
-      xyzz_add<F>(acc, x);
-      if (a.P_in) {
-        XYZZ<F> y = a.P_in[base_in + idx];
-        xyzz_add<F>(pl, y);
-      }
-    }
-    if ((uint32_t)l + a.wbase > 0) xyzz_add<F>(run, acc);
+CTT_HD const XYZZ<F>* pyr_level(const PyrArgs<F>& a, uint32_t w, int l) {
+  if (l == 0) return a.buckets + (uint64_t)w * a.B;
+  return a.pyr + (uint64_t)w * a.B + (a.B - (a.B >> (l - 1)));
+}
+
+// number of tasks (lanes) of pass p per window
+CTT_HD uint32_t pyr_pass_tasks(uint32_t B, int c, int p) {
+  uint32_t n = B >> (p + 1);          // (a) pyramid level p+1
+  uint32_t L = B >> (p + 1);          // (b) odd elements of level p
+  n += (L >= 2) ? L / 2 : 1;
+  for (int l = 0; l < p; l++) {       // (c) halving of earlier trees
+    uint32_t Ll = B >> (l + 1);
+    if (Ll < 2) continue;
+    uint32_t len = (Ll / 2) >> (p - l - 1);
+    if (len >= 2) n += len / 2;
   }
-  for (uint32_t i = 0; i < a.log2s; i++) acc = xyzz_dbl<F>(acc);
-  xyzz_add<F>(run, pl);
-  a.A_out[(uint64_t)w * a.n_out + t] = acc;
-  a.P_out[(uint64_t)w * a.n_out + t] = run;
+  return n;
+}
+
+template <class F>
+CTT_HD void pyr_body(const PyrArgs<F>& a, uint32_t w, uint32_t t) {
+  const uint32_t B = a.B;
+  const int c = a.c, p = a.p;
+  XYZZ<F>* out = a.out + (uint64_t)w * c;
+  // Decode the task into (src1, src2, dst, dst2) first and run ONE addition afterwards, so that the
+  // lanes of a wave that hold different task kinds still execute the (expensive) addition together.
+  const XYZZ<F>* s1 = nullptr;
+  const XYZZ<F>* s2 = nullptr;
+  XYZZ<F>* d1 = nullptr;
+  XYZZ<F>* d2 = nullptr;
+  const uint32_t na = B >> (p + 1);                 // (a) pyramid: level p+1 from level p
+  const uint32_t L = B >> (p + 1);                  // (b) odd elements of level p
+  const uint32_t nb = (L >= 2) ? L / 2 : 1;
+  if (t < na) {
+    const XYZZ<F>* src = pyr_level<F>(a, w, p);
+    s1 = src + 2 * t;
+    s2 = src + 2 * t + 1;
+    d1 = a.pyr + (uint64_t)w * B + (B - (B >> p)) + t;  // level p+1
+    if (p + 1 == c - 1) d2 = out + (c - 1);             // TOP
+  } else if (t - na < nb) {
+    const uint32_t u = t - na;
+    const XYZZ<F>* src = pyr_level<F>(a, w, p);
+    if (L >= 2) {
+      s1 = src + 2 * u + 1;
+      s2 = src + 2 * (u + L / 2) + 1;
+      d1 = a.q + (uint64_t)w * (B / 2) + (B / 2 - (B >> (p + 1))) + u;
+      if (L / 2 == 1) d2 = out + p;
+    } else {
+      s1 = src + 1;   // single odd element: O_p is a copy
+      d1 = out + p;
+    }
+  } else {
+    uint32_t u = t - na - nb;                       // (c) halve the trees started in earlier passes
+    for (int l = 0; l < p; l++) {
+      const uint32_t Ll = B >> (l + 1);
+      if (Ll < 2) continue;
+      const uint32_t len = (Ll / 2) >> (p - l - 1);
+      if (len < 2) continue;
+      const uint32_t nc = len / 2;
+      if (u < nc) {
+        XYZZ<F>* qd = a.q + (uint64_t)w * (B / 2) + (B / 2 - (B >> (l + 1)));
+        s1 = qd + u;
+        s2 = qd + u + nc;
+        d1 = qd + u;
+        if (nc == 1) d2 = out + l;
+        break;
+      }
+      u -= nc;
+    }
+  }
+  if (!s1) return;
+  XYZZ<F> x = *s1;
+  if (s2) {
+    XYZZ<F> y = *s2;
+    xyzz_add<F>(x, y);
+  }
+  *d1 = x;
+  if (d2) *d2 = x;
 }
 
 // ---------------------------------------------------------------------------------------------

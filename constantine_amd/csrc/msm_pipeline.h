@@ -7,6 +7,7 @@
 
 #include <vector>
 
+#include "host_fp64.h"
 #include "msm_bodies.h"
 
 namespace ctt {
@@ -72,13 +73,19 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   return p;
 }
 
-// Horner over the window sums (ec_multi_scalar_mul.nim:250-254; _parallel.nim:199-203)
+// Final Horner (ec_multi_scalar_mul.nim:250-254; _parallel.nim:199-203), fused with the last step of the
+// bucket reduction: per window the device returns O_0..O_{c-2} (sum of the buckets whose index has bit l set)
+// and TOP (sum of all buckets); window sum = sum_l 2^l O_l + TOP, result = sum_w 2^(c*w) * window sum.
 template <class F>
-static inline XYZZ<F> combine_windows(const XYZZ<F>* sums, int W, int c) {
-  XYZZ<F> r = sums[W - 1];
-  for (int w = W - 2; w >= 0; w--) {
-    for (int i = 0; i < c; i++) r = xyzz_dbl<F>(r);
-    xyzz_add<F>(r, sums[w]);
+static inline XYZZ<F> combine_windows_bits(const XYZZ<F>* o, int W, int c) {
+  XYZZ<F> r = XYZZ<F>::inf();
+  for (int w = W - 1; w >= 0; w--) {
+    const XYZZ<F>* ow = o + (size_t)w * c;
+    for (int l = c - 1; l >= 0; l--) {
+      r = xyzz_dbl<F>(r);
+      if (l <= c - 2) xyzz_add<F>(r, ow[l]);
+    }
+    xyzz_add<F>(r, ow[c - 1]);
   }
   return r;
 }
@@ -113,9 +120,12 @@ struct MsmEngine {
   }
 
   // d_coefs: canonical scalars [n][8] (coef_is_fr = false) or Montgomery Fr elements (true), device memory.
-  // d_points: affine Montgomery points, device memory.  Result: the MSM as an XYZZ point on the host.
-  XYZZ<F> run(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points, uint32_t n) {
-    if (n == 0) return XYZZ<F>::inf();  // len == 0 is UB upstream; we return the neutral
+  // d_points: affine Montgomery points, device memory.  Result: the MSM as an XYZZ point on the host
+  // (host arithmetic on 64-bit limbs, same memory layout as the device field).
+  using HF = typename HostField<F>::type;
+  XYZZ<HF> run(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points, uint32_t n) {
+    static_assert(sizeof(XYZZ<HF>) == sizeof(XYZZ<F>), "host/device layouts must match");
+    if (n == 0) return XYZZ<HF>::inf();  // len == 0 is UB upstream; we return the neutral
     MsmPlan p = make_plan(n, C::BITS, opt);
     last_plan = p;
     const uint32_t W = p.W, B = p.B;
@@ -140,6 +150,7 @@ struct MsmEngine {
     uint32_t* d_maxcount = (uint32_t*)need(maxcount, 256);
     bk.memset0(d_maxcount, 4);
     bk.launch_sort(d_digits, d_counts, d_bstart, d_entries, d_maxcount, n, B, p.S, p.slice, W);
+    bk.fetch_u32_async(d_maxcount);  // largest bucket: read back while the accumulation runs
     bk.stage_end(ST_SORT);
 
     bk.stage_begin(ST_ACCUM);
@@ -156,37 +167,27 @@ struct MsmEngine {
     bk.stage_begin(ST_MERGE);
     MergeArgs<F> ma{d_bstart, d_buckets, d_heads, d_tails, d_hkey, d_tkey, d_maxcount, B, p.K, p.G};
     bk.template launch_merge_tail<F>(ma, W);
-    // tree steps: host bound on the chain length is ceil(n/K)+1; kernels exit early on the device bound
-    for (uint32_t d = 1; d < p.G + 1; d <<= 1) bk.template launch_merge_step<F>(ma, W, d);
+    // tree steps over the head chain of a bucket: a bucket of m entries spans at most floor((m-1)/K)+1 heads
+    const uint32_t mc = bk.fetch_u32_wait();
+    const uint32_t chain = mc ? (mc - 1) / p.K + 1 : 0;
+    for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<F>(ma, W, d);
     bk.template launch_merge_final<F>(ma, W);
     bk.stage_end(ST_MERGE);
 
     bk.stage_begin(ST_REDUCE);
-    uint32_t n_in = B;
-    const XYZZ<F>* A_in = d_buckets;
-    const XYZZ<F>* P_in = nullptr;
-    uint32_t wbase = 1;
-    int pp = 0;
-    size_t lvl_cap = (size_t)W * ((B + p.rs - 1) / p.rs) * sizeof(XYZZ<F>);
-    for (int i = 0; i < 2; i++) { need(rA[i], lvl_cap); need(rP[i], lvl_cap); }
-    const XYZZ<F>* d_sums = nullptr;
-    for (;;) {
-      uint32_t n_out = (n_in + p.rs - 1) / p.rs;
-      ReduceArgs<F> ra{A_in, P_in, (XYZZ<F>*)rA[pp].p, (XYZZ<F>*)rP[pp].p, n_in, n_out, p.rs, p.rlog, wbase};
-      bk.template launch_reduce<F>(ra, W);
-      A_in = (const XYZZ<F>*)rA[pp].p;
-      P_in = (const XYZZ<F>*)rP[pp].p;
-      n_in = n_out;
-      wbase = 0;
-      pp ^= 1;
-      if (n_out == 1) { d_sums = P_in; break; }
+    XYZZ<F>* d_pyr = (XYZZ<F>*)need(rA[0], (size_t)W * B * sizeof(XYZZ<F>));
+    XYZZ<F>* d_q = (XYZZ<F>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<F>));
+    XYZZ<F>* d_out = (XYZZ<F>*)need(rP[0], (size_t)W * p.c * sizeof(XYZZ<F>));
+    for (int pass = 0; pass <= p.c - 2; pass++) {
+      PyrArgs<F> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass};
+      bk.template launch_pyr<F>(pa, W, pyr_pass_tasks(B, p.c, pass));
     }
     bk.stage_end(ST_REDUCE);
 
-    std::vector<XYZZ<F>> sums(W);
-    bk.d2h(sums.data(), d_sums, (size_t)W * sizeof(XYZZ<F>));  // synchronises
+    std::vector<XYZZ<HF>> sums((size_t)W * p.c);
+    bk.d2h(sums.data(), d_out, (size_t)W * p.c * sizeof(XYZZ<F>));  // synchronises
     bk.stage_end(ST_TOTAL);
-    return combine_windows<F>(sums.data(), (int)W, p.c);
+    return combine_windows_bits<HF>(sums.data(), (int)W, p.c);
   }
 };
 

@@ -17,6 +17,9 @@ struct EmuBackend {
   void free(void* p) { ::free(p); }
   void memset0(void* p, size_t b) { memset(p, 0, b); }
   void d2h(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
+  uint32_t word = 0;
+  void fetch_u32_async(const uint32_t* d) { word = *d; }
+  uint32_t fetch_u32_wait() { return word; }
   void stage_begin(int) {}
   void stage_end(int) {}
 
@@ -85,8 +88,9 @@ struct EmuBackend {
     for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_final_body<F>(a, w, g);
   }
   template <class F>
-  void launch_reduce(const ReduceArgs<F>& a, uint32_t W) {
-    for (uint32_t w = 0; w < W; w++) for (uint32_t t = 0; t < a.n_out; t++) reduce_body<F>(a, w, t);
+  void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
+    // a pass reads only what earlier passes wrote, except the in-place halving q[t] += q[t+n] (disjoint t)
+    for (uint32_t w = 0; w < W; w++) for (uint32_t t = 0; t < ntasks; t++) pyr_body<F>(a, w, t);
   }
 };
 
@@ -100,8 +104,8 @@ static int emu_msm_t(int coef_is_fr, int out_kind, void* r, const void* coefs, c
   if (rs_log > 0) eng.opt.rs_log = rs_log;
   eng.opt.S = S;
   eng.opt.lanes = 4096;
-  XYZZ<typename C::F> res = eng.run((const uint32_t*)coefs, coef_is_fr != 0, (const Affine<typename C::F>*)points, (uint32_t)n);
-  write_result<typename C::F>(r, res, out_kind);
+  auto res = eng.run((const uint32_t*)coefs, coef_is_fr != 0, (const Affine<typename C::F>*)points, (uint32_t)n);
+  write_result<typename MsmEngine<C, EmuBackend>::HF>(r, res, out_kind);
   if (plan_out && n) {
     plan_out[0] = eng.last_plan.c; plan_out[1] = eng.last_plan.W; plan_out[2] = (int)eng.last_plan.K;
     plan_out[3] = (int)eng.last_plan.G; plan_out[4] = (int)eng.last_plan.S;
