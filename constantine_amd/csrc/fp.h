@@ -33,36 +33,136 @@ namespace ctt {
 
 // ---------------------------------------------------------------------------------------------
 // (hi:lo) += a*b, 96-bit column accumulator
+//
+// Device form: v_mad_u64_u32 (32x32+64, carry-out in VCC) followed by v_addc_co_u32 into the third word.
+// hipcc pads every inline-asm statement with an s_nop (it cannot see what is inside), so the MACs of a
+// column are issued in groups of up to four per statement.
 // ---------------------------------------------------------------------------------------------
 struct Acc3 {
   uint64_t lo;
   uint32_t hi;
 };
 
-CTT_HD void mac(Acc3& acc, uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(acc.lo), "+v"(acc.hi)
-      : "v"(a), "v"(b)
-      : "vcc");
-#else
+#define CTT_MAC_STR(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+
+CTT_HD void mac_host(Acc3& acc, uint32_t a, uint32_t b) {
   uint64_t prod = (uint64_t)a * b;
   acc.lo += prod;
   acc.hi += (acc.lo < prod) ? 1u : 0u;
+}
+
+CTT_HD void mac(Acc3& acc, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(CTT_MAC_STR(2, 3) : "+v"(acc.lo), "+v"(acc.hi) : "v"(a), "v"(b) : "vcc");
+#else
+  mac_host(acc, a, b);
+#endif
+}
+CTT_HD void mac2(Acc3& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(CTT_MAC_STR(2, 3) CTT_MAC_STR(4, 5) : "+v"(acc.lo), "+v"(acc.hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+#else
+  mac_host(acc, a0, b0); mac_host(acc, a1, b1);
+#endif
+}
+CTT_HD void mac3(Acc3& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(CTT_MAC_STR(2, 3) CTT_MAC_STR(4, 5) CTT_MAC_STR(6, 7)
+      : "+v"(acc.lo), "+v"(acc.hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2) : "vcc");
+#else
+  mac_host(acc, a0, b0); mac_host(acc, a1, b1); mac_host(acc, a2, b2);
+#endif
+}
+CTT_HD void mac4(Acc3& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3,
+                 uint32_t b3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(CTT_MAC_STR(2, 3) CTT_MAC_STR(4, 5) CTT_MAC_STR(6, 7) CTT_MAC_STR(8, 9)
+      : "+v"(acc.lo), "+v"(acc.hi)
+      : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
+      : "vcc");
+#else
+  mac_host(acc, a0, b0); mac_host(acc, a1, b1); mac_host(acc, a2, b2); mac_host(acc, a3, b3);
 #endif
 }
 
-// same, b is a compile-time constant of the field (lives in an SGPR on the device)
+// same with the second factor a compile-time constant of the field (lives in an SGPR on the device;
+// gfx9 VOP3 takes no literal and only one SGPR per instruction)
 CTT_HD void mac_k(Acc3& acc, uint32_t a, uint32_t k) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(acc.lo), "+v"(acc.hi)
-      : "v"(a), "s"(k)
-      : "vcc");
+  asm(CTT_MAC_STR(2, 3) : "+v"(acc.lo), "+v"(acc.hi) : "v"(a), "s"(k) : "vcc");
 #else
-  mac(acc, a, k);
+  mac_host(acc, a, k);
 #endif
 }
+CTT_HD void mac2_k(Acc3& acc, uint32_t a0, uint32_t k0, uint32_t a1, uint32_t k1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(CTT_MAC_STR(2, 3) CTT_MAC_STR(4, 5) : "+v"(acc.lo), "+v"(acc.hi) : "v"(a0), "s"(k0), "v"(a1), "s"(k1) : "vcc");
+#else
+  mac_host(acc, a0, k0); mac_host(acc, a1, k1);
+#endif
+}
+CTT_HD void mac3_k(Acc3& acc, uint32_t a0, uint32_t k0, uint32_t a1, uint32_t k1, uint32_t a2, uint32_t k2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(CTT_MAC_STR(2, 3) CTT_MAC_STR(4, 5) CTT_MAC_STR(6, 7)
+      : "+v"(acc.lo), "+v"(acc.hi) : "v"(a0), "s"(k0), "v"(a1), "s"(k1), "v"(a2), "s"(k2) : "vcc");
+#else
+  mac_host(acc, a0, k0); mac_host(acc, a1, k1); mac_host(acc, a2, k2);
+#endif
+}
+CTT_HD void mac4_k(Acc3& acc, uint32_t a0, uint32_t k0, uint32_t a1, uint32_t k1, uint32_t a2, uint32_t k2, uint32_t a3,
+                   uint32_t k3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm(CTT_MAC_STR(2, 3) CTT_MAC_STR(4, 5) CTT_MAC_STR(6, 7) CTT_MAC_STR(8, 9)
+      : "+v"(acc.lo), "+v"(acc.hi)
+      : "v"(a0), "s"(k0), "v"(a1), "s"(k1), "v"(a2), "s"(k2), "v"(a3), "s"(k3)
+      : "vcc");
+#else
+  mac_host(acc, a0, k0); mac_host(acc, a1, k1); mac_host(acc, a2, k2); mac_host(acc, a3, k3);
+#endif
+}
+
+// acc += sum_{i=I}^{END-1} a[i]*b[K-i], grouped four MACs per statement
+template <int K, int I, int END>
+struct MacAB {
+  static CTT_HD void run(Acc3& acc, const uint32_t* a, const uint32_t* b) {
+    if constexpr (END - I >= 4) {
+      mac4(acc, a[I], b[K - I], a[I + 1], b[K - I - 1], a[I + 2], b[K - I - 2], a[I + 3], b[K - I - 3]);
+      MacAB<K, I + 4, END>::run(acc, a, b);
+    } else if constexpr (END - I == 3) {
+      mac3(acc, a[I], b[K - I], a[I + 1], b[K - I - 1], a[I + 2], b[K - I - 2]);
+    } else if constexpr (END - I == 2) {
+      mac2(acc, a[I], b[K - I], a[I + 1], b[K - I - 1]);
+    } else if constexpr (END - I == 1) {
+      mac(acc, a[I], b[K - I]);
+    }
+  }
+};
+
+// acc += sum_{i=I}^{END-1} m[i]*P[K-i]; zero limbs of the modulus are skipped at compile time
+// (Pallas/Vesta: three of eight limbs are zero)
+template <class PP, int K, int I, int END>
+struct MacMP {
+  static constexpr bool nz(int i) { return i < END && PP::P[K - i] != 0u; }
+  static CTT_HD void run(Acc3& acc, const uint32_t* m) {
+    if constexpr (I >= END) {
+      return;
+    } else if constexpr (!nz(I)) {
+      MacMP<PP, K, I + 1, END>::run(acc, m);
+    } else if constexpr (nz(I + 1) && nz(I + 2) && nz(I + 3)) {
+      mac4_k(acc, m[I], PP::P[K - I], m[I + 1], PP::P[K - I - 1], m[I + 2], PP::P[K - I - 2], m[I + 3], PP::P[K - I - 3]);
+      MacMP<PP, K, I + 4, END>::run(acc, m);
+    } else if constexpr (nz(I + 1) && nz(I + 2)) {
+      mac3_k(acc, m[I], PP::P[K - I], m[I + 1], PP::P[K - I - 1], m[I + 2], PP::P[K - I - 2]);
+      MacMP<PP, K, I + 3, END>::run(acc, m);
+    } else if constexpr (nz(I + 1)) {
+      mac2_k(acc, m[I], PP::P[K - I], m[I + 1], PP::P[K - I - 1]);
+      MacMP<PP, K, I + 2, END>::run(acc, m);
+    } else {
+      mac_k(acc, m[I], PP::P[K - I]);
+      MacMP<PP, K, I + 1, END>::run(acc, m);
+    }
+  }
+};
 
 CTT_HD void acc_shift(Acc3& acc) {
   acc.lo = (acc.lo >> 32) | ((uint64_t)acc.hi << 32);
@@ -180,31 +280,28 @@ struct Fp {
 
   // Montgomery product a*b*R^-1 mod p, product scanning with interleaved reduction (FIPS form of
   // limbs_montgomery.nim:268-310); result fully reduced.
+  template <int K>
+  static CTT_HD void mul_col(Acc3& acc, const uint32_t* a, const uint32_t* b, uint32_t* m, uint32_t* t) {
+    if constexpr (K < N) {
+      MacAB<K, 0, K + 1>::run(acc, a, b);
+      MacMP<PP, K, 0, K>::run(acc, m);
+      m[K] = (uint32_t)acc.lo * PP::M0INV;
+      mac_k(acc, m[K], PP::P[0]);
+    } else {
+      MacAB<K, K - N + 1, N>::run(acc, a, b);
+      MacMP<PP, K, K - N + 1, N>::run(acc, m);
+      t[K - N] = (uint32_t)acc.lo;
+    }
+    acc_shift(acc);
+    if constexpr (K + 1 < 2 * N) mul_col<K + 1>(acc, a, b, m, t);
+  }
   CTT_HD static Fp mul(const Fp& a, const Fp& b) {
     Acc3 acc;
     acc.lo = 0;
     acc.hi = 0;
     uint32_t m[N];
     uint32_t t[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-#pragma unroll
-      for (int i = 0; i <= k; i++) mac(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-      for (int i = 0; i < k; i++) mac_k(acc, m[i], PP::P[k - i]);
-      m[k] = (uint32_t)acc.lo * PP::M0INV;
-      mac_k(acc, m[k], PP::P[0]);
-      acc_shift(acc);
-    }
-#pragma unroll
-    for (int k = N; k < 2 * N; k++) {
-#pragma unroll
-      for (int i = k - N + 1; i < N; i++) mac(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-      for (int i = k - N + 1; i < N; i++) mac_k(acc, m[i], PP::P[k - i]);
-      t[k - N] = (uint32_t)acc.lo;
-      acc_shift(acc);
-    }
+    mul_col<0>(acc, a.l, b.l, m, t);
     return reduce_once(t, (uint32_t)acc.lo);
   }
 
@@ -242,12 +339,14 @@ struct Fp {
       if ((k & 1) == 0 && (k >> 1) < N) mac(acc, a.l[k >> 1], a.l[k >> 1]);
       if (k < N) {
 #pragma unroll
-        for (int i = 0; i < k; i++) mac_k(acc, m[i], PP::P[k - i]);
+        for (int i = 0; i < k; i++)
+          if (PP::P[k - i] != 0u) mac_k(acc, m[i], PP::P[k - i]);
         m[k] = (uint32_t)acc.lo * PP::M0INV;
         mac_k(acc, m[k], PP::P[0]);
       } else {
 #pragma unroll
-        for (int i = k - N + 1; i < N; i++) mac_k(acc, m[i], PP::P[k - i]);
+        for (int i = k - N + 1; i < N; i++)
+          if (PP::P[k - i] != 0u) mac_k(acc, m[i], PP::P[k - i]);
         t[k - N] = (uint32_t)acc.lo;
       }
       acc_shift(acc);
