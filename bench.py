@@ -73,23 +73,38 @@ def main():
     d_scal = torch.from_numpy(scal).cuda()
     torch.cuda.synchronize()
 
-    def step():
-        return parallel.msm_sharded(curve, lambda: eng.msm(curve, d_scal, d_points, n, coord="aff"))
+    # One step = one complete MSM.  Two steps are kept in flight: the GPU work of step i+1 is enqueued before the
+    # host tail of step i (Horner over windows, affine normalisation, partial-sum exchange) runs, so the GPU never
+    # waits for the CPU.  Every step's result is produced inside the timed region.
+    def submit():
+        return eng.submit(curve, d_scal, d_points, n)
+
+    def finish(ticket):
+        return parallel.msm_sharded(curve, lambda: eng.finish(ticket, coord="aff"))
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        eng.sync()
 
-    for _ in range(args.warmup):
-        res = step()
+    def run_steps(k, acc=None):
+        res = None
+        pending = submit() if k > 0 else None
+        for i in range(k):
+            nxt = submit() if i + 1 < k else None
+            res = finish(pending)
+            if acc is not None:
+                for key, v in eng.last_timings().items():   # HIP events recorded on the engine's stream
+                    acc[key] = acc.get(key, 0.0) + v
+            pending = nxt
+        return res
+
+    run_steps(args.warmup)
     stage_acc = {}
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        for k, v in eng.last_timings().items():   # HIP events recorded on the engine's stream
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    res = run_steps(args.steps, stage_acc)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:

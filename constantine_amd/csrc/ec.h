@@ -9,8 +9,13 @@
 // Input points are EC_ShortW_Aff with neutral encoded as (0,0) (ec_shortweierstrass_affine.nim:47-62).
 // All exceptional cases (either operand neutral, P == Q, P == -Q) are handled, as the reference's
 // *_vartime formulas do (ec_shortweierstrass_jacobian.nim:798-896).
+//
+// The formulas are written once for both field flavours.  For the carry-free field (fpu.h) values are only
+// bounded by multiples of p, tracked statically here in units of M = F::MULB (a product is < M*p):
+//     affine input x, y < M;   stored XYZZ:  X < 4M,  Y < 2M,  ZZ, ZZZ < M.
+// fsub<F,B>(a,b) = a - b + B*p needs b < B*p and yields bound(a)+B; the canonical field ignores B.
 #pragma once
-#include "fp.h"
+#include "fpu.h"
 
 namespace ctt {
 
@@ -32,18 +37,19 @@ struct XYZZ {
   }
 };
 
-// 2*(x,y) for an affine, non-neutral point with y != 0 (y == 0 gives ZZ = 0, i.e. the neutral)
+// 2*(x,y) for an affine, non-neutral point (x, y < M); y == 0 gives ZZ = 0, i.e. the neutral
 template <class F>
 CTT_HD XYZZ<F> xyzz_mdbl(const F& x, const F& y) {
-  F U = F::dbl(y);
-  F V = F::sqr(U);
+  constexpr int M = F::MULB;
+  F U = F::dbl(y);                               // < 2M
+  F V = F::sqr(U);                               // < M
   F W = F::mul(U, V);
   F S = F::mul(x, V);
   F xx = F::sqr(x);
-  F M = F::add(F::dbl(xx), xx);
+  F Mm = F::add(F::dbl(xx), xx);                 // < 3M
   XYZZ<F> r;
-  r.x = F::sub(F::sqr(M), F::dbl(S));
-  r.y = F::sub(F::mul(M, F::sub(S, r.x)), F::mul(W, y));
+  r.x = fsub<F, 2 * M>(F::sqr(Mm), F::dbl(S));   // < 3M
+  r.y = fsub<F, M>(F::mul(Mm, fsub<F, 3 * M>(S, r.x)), F::mul(W, y));  // < 2M
   r.zz = V;
   r.zzz = W;
   return r;
@@ -51,36 +57,36 @@ CTT_HD XYZZ<F> xyzz_mdbl(const F& x, const F& y) {
 
 template <class F>
 CTT_HD_NOINLINE XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+  constexpr int M = F::MULB;
   if (p.is_inf()) return p;
-  F U = F::dbl(p.y);
+  F U = F::dbl(p.y);                             // < 4M
   F V = F::sqr(U);
   F W = F::mul(U, V);
   F S = F::mul(p.x, V);
   F xx = F::sqr(p.x);
-  F M = F::add(F::dbl(xx), xx);
+  F Mm = F::add(F::dbl(xx), xx);                 // < 3M
   XYZZ<F> r;
-  r.x = F::sub(F::sqr(M), F::dbl(S));
-  r.y = F::sub(F::mul(M, F::sub(S, r.x)), F::mul(W, p.y));
+  r.x = fsub<F, 2 * M>(F::sqr(Mm), F::dbl(S));   // < 3M
+  r.y = fsub<F, M>(F::mul(Mm, fsub<F, 3 * M>(S, r.x)), F::mul(W, p.y));  // < 2M
   r.zz = F::mul(V, p.zz);
   r.zzz = F::mul(W, p.zzz);
   return r;
 }
 
-// exceptional case of the mixed addition: same x. equal -> doubling of the affine point, opposite -> neutral
+// exceptional case of the mixed addition: same x. equal -> doubling of the affine point, opposite -> neutral.
+// Returns by value (the accumulator of the hot loop must never have its address taken: it would live in scratch).
 template <class F>
-CTT_HD_NOINLINE void xyzz_madd_same_x(XYZZ<F>& acc, const F& qx, const F& qy, bool same_y) {
-  if (same_y) {
-    acc = xyzz_mdbl<F>(qx, qy);
-  } else {
-    acc = XYZZ<F>::inf();
-  }
+CTT_HD_NOINLINE XYZZ<F> xyzz_madd_same_x(F qx, F qy, bool same_y) {
+  if (same_y) return xyzz_mdbl<F>(qx, qy);
+  return XYZZ<F>::inf();
 }
 
 // acc += (neg ? -q : q), q affine
 template <class F>
 CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
+  constexpr int M = F::MULB;
   if (q.is_inf()) return;
-  F qy = F::cneg(q.y, neg);
+  F qy = fcneg<F, M>(q.y, neg);                  // < M
   if (acc.is_inf()) {
     acc.x = q.x;
     acc.y = qy;
@@ -88,19 +94,19 @@ CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
     acc.zzz = F::one();
     return;
   }
-  F U2 = F::mul(q.x, acc.zz);
+  F U2 = F::mul(q.x, acc.zz);                    // < M
   F S2 = F::mul(qy, acc.zzz);
-  F P = F::sub(U2, acc.x);
-  F R = F::sub(S2, acc.y);
-  if (P.is_zero()) {  // P == +-Q: rare, out of line
-    xyzz_madd_same_x<F>(acc, q.x, qy, R.is_zero());
+  F P = fsub<F, 4 * M>(U2, acc.x);               // < 5M
+  F R = fsub<F, 2 * M>(S2, acc.y);               // < 3M
+  if (fis_zero_modp<F, 5 * M>(P)) {              // P == +-Q: rare, out of line
+    acc = xyzz_madd_same_x<F>(q.x, qy, fis_zero_modp<F, 3 * M>(R));
     return;
   }
   F PP = F::sqr(P);
   F PPP = F::mul(P, PP);
   F Q = F::mul(acc.x, PP);
-  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.y, PPP));
+  F X3 = fsub<F, 2 * M>(fsub<F, M>(F::sqr(R), PPP), F::dbl(Q));        // < 4M
+  F Y3 = fsub<F, M>(F::mul(R, fsub<F, 4 * M>(Q, X3)), F::mul(acc.y, PPP));  // < 2M
   acc.x = X3;
   acc.y = Y3;
   acc.zz = F::mul(acc.zz, PP);
@@ -110,6 +116,7 @@ CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
 // acc += q, both XYZZ  (not on the hot path: kept out of line to bound code size / compile time)
 template <class F>
 CTT_HD_NOINLINE void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& q) {
+  constexpr int M = F::MULB;
   if (q.is_inf()) return;
   if (acc.is_inf()) {
     acc = q;
@@ -119,10 +126,10 @@ CTT_HD_NOINLINE void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& q) {
   F U2 = F::mul(q.x, acc.zz);
   F S1 = F::mul(acc.y, q.zzz);
   F S2 = F::mul(q.y, acc.zzz);
-  F P = F::sub(U2, U1);
-  F R = F::sub(S2, S1);
-  if (P.is_zero()) {
-    if (R.is_zero()) {
+  F P = fsub<F, M>(U2, U1);                      // < 2M
+  F R = fsub<F, M>(S2, S1);                      // < 2M
+  if (fis_zero_modp<F, 2 * M>(P)) {
+    if (fis_zero_modp<F, 2 * M>(R)) {
       acc = xyzz_dbl<F>(acc);
     } else {
       acc = XYZZ<F>::inf();
@@ -132,15 +139,16 @@ CTT_HD_NOINLINE void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& q) {
   F PP = F::sqr(P);
   F PPP = F::mul(P, PP);
   F Q = F::mul(U1, PP);
-  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+  F X3 = fsub<F, 2 * M>(fsub<F, M>(F::sqr(R), PPP), F::dbl(Q));       // < 4M
+  F Y3 = fsub<F, M>(F::mul(R, fsub<F, 4 * M>(Q, X3)), F::mul(S1, PPP));   // < 2M
   acc.x = X3;
   acc.y = Y3;
   acc.zz = F::mul(F::mul(acc.zz, q.zz), PP);
   acc.zzz = F::mul(F::mul(acc.zzz, q.zzz), PPP);
 }
 
-// x = X/ZZ, y = Y/ZZZ (fromJacobianExtended_vartime, jacobian_extended.nim:353-379, then affine)
+// x = X/ZZ, y = Y/ZZZ (fromJacobianExtended_vartime, jacobian_extended.nim:353-379, then affine).
+// Canonical fields only (host tail, input generator).
 template <class F>
 CTT_HD Affine<F> xyzz_to_affine(const XYZZ<F>& p) {
   if (p.is_inf()) return Affine<F>::inf();

@@ -177,6 +177,8 @@ struct Fp {
   using Params = PP;
   static constexpr int N = PP::N;
   static constexpr int NBYTES = 4 * N;
+  static constexpr bool UNSAT = false;  // canonical representation: always in [0,p)
+  static constexpr int MULB = 1;
   uint32_t l[N];
 
   CTT_HD static Fp zero() {
@@ -386,6 +388,8 @@ template <class F>
 struct Fp2 {
   using Base = F;
   static constexpr int NBYTES = 2 * F::NBYTES;
+  static constexpr bool UNSAT = false;
+  static constexpr int MULB = 1;
   F c0, c1;
 
   CTT_HD static Fp2 zero() { return {F::zero(), F::zero()}; }

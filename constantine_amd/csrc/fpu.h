@@ -1,0 +1,246 @@
+// fpu.h -- carry-free ("unsaturated") prime field for the hot kernels: NL limbs of LB < 32 bits.
+//
+// Why: on gfx950 the carry instruction of a saturated 32-bit-limb multiplier (v_addc_co_u32) costs almost
+// as much issue time as the multiplier itself (v_mad_u64_u32), see profiles/microbench_r01.jsonl.  With
+// LB-bit limbs a whole product-scanning column fits a 64-bit accumulator, so the Montgomery multiplication
+// (same algorithm as the reference's, limbs_montgomery.nim:268-310, radix 2^LB instead of 2^64) is nothing but
+// v_mad_u64_u32, plus one mask/shift per column: 392 multiplies and no carries for BLS12-381 (LB = 28,
+// NL = 14) against 288 multiplies + 288 carries.
+//
+// Representation: value v = sum l[i] * 2^(LB*i) with v == x * R' (mod p), R' = 2^(LB*NL).  Elements are NOT
+// kept in [0,p): every operation returns limbs normalised to < 2^LB (top limb takes the excess) and a value
+// bounded by a small multiple of p that the caller tracks statically:
+//     mul, sqr   : result < 2p   provided  a*b < R'*p   (R'/p >= 2^RP_OVER_P_LOG2: 2^11 for BLS12-381, 2^7 for
+//                                                        the 254/255-bit fields; operands up to ~11p are fine)
+//     add        : bound(a) + bound(b)
+//     sub<B>     : a - b + B*p, needs b < B*p;  result < bound(a) + B
+// Conversions to/from the reference's representation (Montgomery R = 2^(64L), saturated limbs) happen once per
+// point on the way in (from_sat) and once per returned point on the host (HostField, host_fp64.h).
+#pragma once
+#include "fp.h"
+
+namespace ctt {
+
+template <class UP>
+struct FpU {
+  using Params = UP;
+  using Sat = Fp<typename UP::Sat>;
+  static constexpr int NL = UP::NL;
+  static constexpr int LB = UP::LB;
+  static constexpr uint32_t MASK = UP::MASK;
+  static constexpr int N = NL;        // limb count (for generic helpers)
+  static constexpr int MULB = 2;      // mul/sqr outputs are < MULB * p
+  static constexpr bool UNSAT = true;
+  uint32_t l[NL];
+
+  CTT_HD static FpU zero() {
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = 0;
+    return r;
+  }
+  CTT_HD static FpU one() {
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = UP::ONE[i];
+    return r;
+  }
+  // raw test: every limb zero.  Exact for values we set to zero ourselves (neutral flags, (0,0) inputs);
+  // a value that is merely == 0 (mod p) needs is_zero_modp.
+  CTT_HD bool is_zero() const {
+    uint32_t a = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) a |= l[i];
+    return a == 0;
+  }
+  CTT_HD static FpU select(bool c, const FpU& a, const FpU& b) {
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+  }
+
+  // limbs of k*p in canonical radix-2^LB form
+  struct KP { uint32_t l[NL]; };
+  static constexpr KP kp(int k) {
+    KP r{};
+    uint64_t c = 0;
+    for (int i = 0; i < NL; i++) {
+      uint64_t v = (uint64_t)UP::P[i] * (uint64_t)k + c;
+      r.l[i] = (i == NL - 1) ? (uint32_t)v : (uint32_t)(v & MASK);
+      c = v >> LB;
+    }
+    return r;
+  }
+
+  // value == 0 (mod p), for a normalised element known to be < B*p
+  template <int B>
+  CTT_HD bool is_zero_modp() const {
+    // quick reject on the low limb: v = k*p  =>  l[0] == (k*p) mod 2^LB for some k < B
+    bool maybe = false;
+#pragma unroll
+    for (int k = 0; k < B; k++) maybe |= (l[0] == kp(k).l[0]);
+    if (!maybe) return false;
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      constexpr_for_kp_cmp(k, hit);
+    }
+    return hit;
+  }
+  CTT_HD void constexpr_for_kp_cmp(int k, bool& hit) const {
+    uint32_t d = 0;
+    uint64_t c = 0;
+    for (int i = 0; i < NL; i++) {  // rare path: recompute k*p limb by limb
+      uint64_t v = (uint64_t)UP::P[i] * (uint64_t)k + c;
+      uint32_t li = (i == NL - 1) ? (uint32_t)v : (uint32_t)(v & MASK);
+      c = v >> LB;
+      d |= l[i] ^ li;
+    }
+    hit |= (d == 0);
+  }
+
+  // carry propagation: limbs < 2^LB afterwards (the top limb keeps the excess)
+  CTT_HD void normalise() {
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+      uint32_t c = l[i] >> LB;
+      l[i] &= MASK;
+      l[i + 1] += c;
+    }
+  }
+
+  CTT_HD static FpU add(const FpU& a, const FpU& b) {
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+    r.normalise();
+    return r;
+  }
+  CTT_HD static FpU dbl(const FpU& a) {
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] << 1;
+    r.normalise();
+    return r;
+  }
+
+  // a - b + B*p  (b normalised and < B*p).  B*p is spread over the limbs as
+  // (c0 + 2^LB, c1 + 2^LB - 1, ..., c_top - 1) so that no limb goes negative before the carries are propagated.
+  template <int B>
+  CTT_HD static FpU sub(const FpU& a, const FpU& b) {
+    constexpr KP c = kp(B);
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const uint32_t bias = (i == 0) ? c.l[0] + (1u << LB) : (i == NL - 1) ? c.l[i] - 1u : c.l[i] + (1u << LB) - 1u;
+      r.l[i] = a.l[i] + bias - b.l[i];
+    }
+    r.normalise();
+    return r;
+  }
+  template <int B>
+  CTT_HD static FpU neg(const FpU& a) { return sub<B>(zero(), a); }
+  // conditional negation; the negated branch is B*p - a (a < B*p).  A raw zero stays a raw zero.
+  template <int B>
+  CTT_HD static FpU cneg(const FpU& a, bool c) {
+    FpU n = sub<B>(zero(), a);
+    return select(c, n, a);
+  }
+
+  // Montgomery product a*b/R' (mod p), radix 2^LB, product scanning; limbs of a, b < 2^30, a*b < R'*p.
+  CTT_HD static FpU mul(const FpU& a, const FpU& b) {
+    uint64_t acc = 0;
+    uint32_t m[NL];
+    FpU t;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+      for (int i = 0; i < k; i++)
+        if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
+      m[k] = ((uint32_t)acc * UP::M0INV) & MASK;
+      acc += (uint64_t)m[k] * UP::P[0];
+      acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; i++)
+        if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
+      t.l[k - NL] = (uint32_t)acc & MASK;
+      acc >>= LB;
+    }
+    t.l[NL - 1] = (uint32_t)acc;
+    return t;
+  }
+
+  // square: cross products once with a doubled operand (2*a_i < 2^31 fits)
+  CTT_HD static FpU sqr(const FpU& a) {
+    uint64_t acc = 0;
+    uint32_t m[NL];
+    uint32_t a2[NL];
+    FpU t;
+#pragma unroll
+    for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const int j = k - i;
+        if (j > i && j < NL) acc += (uint64_t)a2[i] * a.l[j];
+      }
+      if ((k & 1) == 0) acc += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
+      if (k < NL) {
+#pragma unroll
+        for (int i = 0; i < k; i++)
+          if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
+        m[k] = ((uint32_t)acc * UP::M0INV) & MASK;
+        acc += (uint64_t)m[k] * UP::P[0];
+      } else {
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++)
+          if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
+        t.l[k - NL] = (uint32_t)acc & MASK;
+      }
+      acc >>= LB;
+    }
+    t.l[NL - 1] = (uint32_t)acc;
+    return t;
+  }
+
+  // ---- conversions --------------------------------------------------------------------------------
+  // bits [pos, pos+LB) of a little-endian 32-bit limb array of n words
+  CTT_HD static uint32_t bits_at(const uint32_t* w, int n, int pos) {
+    const int word = pos >> 5, sh = pos & 31;
+    uint32_t v = word < n ? w[word] >> sh : 0u;
+    if (sh + LB > 32 && word + 1 < n) v |= w[word + 1] << (32 - sh);
+    return v & MASK;
+  }
+  // reference representation (Montgomery R, saturated, < p)  ->  this one (Montgomery R'); (raw) zero stays zero
+  CTT_HD static FpU from_sat(const Sat& s) {
+    FpU r, c;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      r.l[i] = bits_at(s.l, Sat::N, LB * i);
+      c.l[i] = UP::C_IN[i];
+    }
+    return mul(r, c);
+  }
+};
+
+// Field-generic spellings used by ec.h: saturated fields ignore the bias/bound parameters.
+template <class F, int B> CTT_HD F fsub(const F& a, const F& b) {
+  if constexpr (F::UNSAT) return F::template sub<B>(a, b); else return F::sub(a, b);
+}
+template <class F, int B> CTT_HD F fcneg(const F& a, bool c) {
+  if constexpr (F::UNSAT) return F::template cneg<B>(a, c); else return F::cneg(a, c);
+}
+template <class F, int B> CTT_HD bool fis_zero_modp(const F& a) {
+  if constexpr (F::UNSAT) return a.template is_zero_modp<B>(); else return a.is_zero();
+}
+
+}  // namespace ctt

@@ -30,6 +30,11 @@ __global__ void k_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
 static constexpr int ACCUM_BLOCK = 64;
 static constexpr int EC_BLOCK = 64;
 
+template <class F, class FD>
+__global__ void k_convert_points(const Affine<F>* in, Affine<FD>* out, uint32_t n) {
+  convert_point_body<F, FD>(in, out, n, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 template <class F>
 __global__ void __launch_bounds__(ACCUM_BLOCK) k_accum(AccumArgs<F> a) {
   accum_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
@@ -57,6 +62,25 @@ __global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t
   gen_point_body<typename C::F>(G, seed, first, n, out, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// probe of the device field FD: inputs in the reference representation, output = raw FD limbs
+// (op 0 mul, 1 sqr, 2 add, 3 sub<2>, 4 conversion only)
+template <class F, class FD>
+__global__ void k_field_op_dev(int op, const F* a, const F* b, FD* r, uint32_t n) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  if constexpr (FD::UNSAT) {
+    FD x = FD::from_sat(a[j]), y = FD::from_sat(b[j]), o;
+    switch (op) {
+      case 0: o = FD::mul(x, y); break;
+      case 1: o = FD::sqr(x); break;
+      case 2: o = FD::add(x, y); break;
+      case 3: o = FD::template sub<2>(x, y); break;
+      default: o = x; break;
+    }
+    r[j] = o;
+  }
+}
+
 // field-op probe for the GPU unit tests: op 0 mul, 1 sqr, 2 add, 3 sub, 4 neg
 template <class F>
 __global__ void k_field_op(int op, const F* a, const F* b, F* r, uint32_t n) {
@@ -81,8 +105,9 @@ struct HipBackend {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int num_cu = 256;
-  hipEvent_t ev_begin[ST_COUNT], ev_end[ST_COUNT];
-  bool ev_used[ST_COUNT];
+  hipEvent_t ev_begin[2][ST_COUNT], ev_end[2][ST_COUNT];  // per in-flight slot
+  bool ev_used[2][ST_COUNT];
+  hipEvent_t ev_done[2];
   float stage_ms[ST_COUNT];
 
   void init(int dev);  // msm_engine.hip
@@ -94,10 +119,17 @@ struct HipBackend {
   }
   void free(void* p) { HIP_CHECK(hipFree(p)); }
   void memset0(void* p, size_t b) { HIP_CHECK(hipMemsetAsync(p, 0, b, stream)); }
-  void d2h(void* dst, const void* src, size_t b) {
-    HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+  void* alloc_host(size_t b) {
+    void* p = nullptr;
+    HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocDefault));
+    return p;
   }
+  void free_host(void* p) { HIP_CHECK(hipHostFree(p)); }
+  void d2h_async(int slot, void* dst_pinned, const void* src, size_t b) {
+    HIP_CHECK(hipMemcpyAsync(dst_pinned, src, b, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipEventRecord(ev_done[slot], stream));
+  }
+  void d2h_wait(int slot) { HIP_CHECK(hipEventSynchronize(ev_done[slot])); }
   // small device->host word, overlapped with kernels launched after it
   uint32_t* h_word = nullptr;
   hipEvent_t ev_word = nullptr;
@@ -113,16 +145,17 @@ struct HipBackend {
     HIP_CHECK(hipEventSynchronize(ev_word));
     return *h_word;
   }
-  void stage_begin(int s) {
-    HIP_CHECK(hipEventRecord(ev_begin[s], stream));
-    ev_used[s] = true;
+  void stage_begin(int slot, int s) {
+    HIP_CHECK(hipEventRecord(ev_begin[slot][s], stream));
+    ev_used[slot][s] = true;
   }
-  void stage_end(int s) { HIP_CHECK(hipEventRecord(ev_end[s], stream)); }
-  void collect_timings() {
+  void stage_end(int slot, int s) { HIP_CHECK(hipEventRecord(ev_end[slot][s], stream)); }
+  // stage times of the MSM that used `slot` (call after its finish())
+  void collect_timings(int slot) {
     for (int i = 0; i < ST_COUNT; i++) {
-      if (!ev_used[i]) continue;
-      HIP_CHECK(hipEventSynchronize(ev_end[i]));
-      HIP_CHECK(hipEventElapsedTime(&stage_ms[i], ev_begin[i], ev_end[i]));
+      if (!ev_used[slot][i]) continue;
+      HIP_CHECK(hipEventSynchronize(ev_end[slot][i]));
+      HIP_CHECK(hipEventElapsedTime(&stage_ms[i], ev_begin[slot][i], ev_end[slot][i]));
     }
   }
 
@@ -140,6 +173,11 @@ struct HipBackend {
   template <class Fr>
   void launch_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
     hipLaunchKernelGGL(k_fr_from_mont<Fr>, grid1(n, 256), dim3(256), 0, stream, in, out, n);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F, class FD>
+  void launch_convert(const Affine<F>* in, Affine<FD>* out, uint32_t n) {
+    hipLaunchKernelGGL((k_convert_points<F, FD>), grid1(n, 256), dim3(256), 0, stream, in, out, n);
     HIP_CHECK(hipGetLastError());
   }
   void launch_digits(const DigitsArgs& a);  // msm_engine.hip
@@ -184,6 +222,10 @@ struct CurveOps {
   // runs one MSM on device-resident inputs, writes r (host) in out_kind coordinates, fills plan[6]
   void (*run)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
               void* r_host, int out_kind, int* plan);
+  // split form: at most two MSMs in flight per engine; submit returns the slot (0/1)
+  int (*submit)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
+                int* plan);
+  void (*finish)(void* eng, int slot, void* r_host, int out_kind);
   void (*gen_points)(HipBackend* bk, uint64_t seed, uint64_t first, uint32_t n, void* d_out);
   void (*field_op)(HipBackend* bk, int op, const void* d_a, const void* d_b, void* d_r, uint32_t n);
   // host-only: r_aff = sum of n affine points (combining the per-GPU partial results of a sharded MSM,
@@ -194,10 +236,11 @@ struct CurveOps {
 template <class C>
 struct CurveImpl {
   using F = typename C::F;
+  using FD = typename C::FD;
   using Engine = MsmEngine<C, HipBackend>;
   static void* create(HipBackend* bk) {
     Engine* e = new Engine(*bk);
-    e->opt.lanes = bk->template resident_lanes<F>();
+    e->opt.lanes = bk->template resident_lanes<FD>();
     return e;
   }
   static void destroy(void* e) { delete (Engine*)e; }
@@ -210,6 +253,23 @@ struct CurveImpl {
     auto res = e.run((const uint32_t*)d_coefs, coef_is_fr != 0, (const Affine<F>*)d_points, n);
     const MsmPlan& p = e.last_plan;
     plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
+    plan[6] = e.next_slot ^ 1;  // slot this MSM used
+    write_result<typename Engine::HF>(r_host, res, out_kind);
+  }
+  static int submit(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
+                    int* plan) {
+    Engine& e = *(Engine*)eng;
+    uint32_t lanes = e.opt.lanes;
+    e.opt = *opt;
+    e.opt.lanes = lanes;
+    int sl = e.submit((const uint32_t*)d_coefs, coef_is_fr != 0, (const Affine<F>*)d_points, n);
+    const MsmPlan& p = e.last_plan;
+    plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
+    return sl;
+  }
+  static void finish(void* eng, int slot, void* r_host, int out_kind) {
+    Engine& e = *(Engine*)eng;
+    auto res = e.finish(slot);
     write_result<typename Engine::HF>(r_host, res, out_kind);
   }
   static void gen_points(HipBackend* bk, uint64_t seed, uint64_t first, uint32_t n, void* d_out) {
@@ -219,6 +279,13 @@ struct CurveImpl {
     HIP_CHECK(hipStreamSynchronize(bk->stream));
   }
   static void field_op(HipBackend* bk, int op, const void* d_a, const void* d_b, void* d_r, uint32_t n) {
+    if (op >= 16) {  // device-field probe (raw FD limbs out); only meaningful when FD != F
+      hipLaunchKernelGGL((k_field_op_dev<F, FD>), dim3((n + 255) / 256), dim3(256), 0, bk->stream, op - 16, (const F*)d_a,
+                         (const F*)d_b, (FD*)d_r, n);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(bk->stream));
+      return;
+    }
     hipLaunchKernelGGL(k_field_op<F>, dim3((n + 255) / 256), dim3(256), 0, bk->stream, op, (const F*)d_a, (const F*)d_b,
                        (F*)d_r, n);
     HIP_CHECK(hipGetLastError());
@@ -232,7 +299,7 @@ struct CurveImpl {
     write_result<HF>(r_host, acc, out_kind);
   }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, run, gen_points, field_op, ec_sum_affine};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, run, submit, finish, gen_points, field_op, ec_sum_affine};
     return &o;
   }
 };

@@ -6,7 +6,9 @@
 // the engine does on the CPU (about 2*W*c group operations per MSM, the serial tail the reference runs
 // at ec_multi_scalar_mul.nim:250-254).
 #pragma once
-#include "fp.h"
+#include <string.h>
+
+#include "ec.h"
 
 namespace ctt {
 
@@ -15,6 +17,8 @@ struct Fp64 {
   using Params = PP;
   static constexpr int N = PP::N / 2;
   static constexpr int NBYTES = 8 * N;
+  static constexpr bool UNSAT = false;
+  static constexpr int MULB = 1;
   typedef unsigned __int128 u128;
   uint64_t l[N];
 
@@ -126,9 +130,65 @@ struct Fp64 {
   }
 };
 
-// device field type -> host field type with the same memory layout
+// device field type -> host field type (canonical Montgomery form of the reference, 64-bit limbs)
 template <class F> struct HostField;
-template <class PP> struct HostField<Fp<PP>> { using type = Fp64<PP>; };
-template <class PP> struct HostField<Fp2<Fp<PP>>> { using type = Fp2<Fp64<PP>>; };
+template <class PP> struct HostField<Fp<PP>> {
+  using type = Fp64<PP>;
+  static inline type conv(const Fp<PP>& a) {  // same bytes
+    type r;
+    memcpy(r.l, a.l, sizeof(r.l));
+    return r;
+  }
+};
+template <class PP> struct HostField<Fp2<Fp<PP>>> {
+  using type = Fp2<Fp64<PP>>;
+  static inline type conv(const Fp2<Fp<PP>>& a) { return {HostField<Fp<PP>>::conv(a.c0), HostField<Fp<PP>>::conv(a.c1)}; }
+};
+// carry-free device field: value = x*R' (mod p), not reduced -> reduce, then one Montgomery product with
+// C_OUT = R^2/R' gives x*R (fpu.h)
+template <class UP> struct HostField<FpU<UP>> {
+  using PP = typename UP::Sat;
+  using type = Fp64<PP>;
+  static inline type conv(const FpU<UP>& a) {
+    constexpr int N = type::N;
+    typedef unsigned __int128 u128;
+    uint64_t v[N + 1];
+    for (int i = 0; i <= N; i++) v[i] = 0;
+    for (int i = 0; i < UP::NL; i++) {  // v += l[i] << (LB*i)
+      const int pos = UP::LB * i, w = pos >> 6, sh = pos & 63;
+      u128 x = (u128)a.l[i] << sh;
+      uint64_t c = 0;
+      for (int j = w; j <= N && (x != 0 || c != 0); j++) {
+        u128 s = (u128)v[j] + (uint64_t)x + c;
+        v[j] = (uint64_t)s;
+        c = (uint64_t)(s >> 64);
+        x >>= 64;
+      }
+    }
+    for (;;) {  // v < (small multiple of p): subtract p until v < p
+      uint64_t d[N + 1];
+      uint64_t bw = 0;
+      for (int i = 0; i <= N; i++) {
+        u128 x = (u128)v[i] - (i < N ? type::P(i) : 0) - bw;
+        d[i] = (uint64_t)x;
+        bw = (uint64_t)(x >> 64) & 1;
+      }
+      if (bw) break;
+      for (int i = 0; i <= N; i++) v[i] = d[i];
+    }
+    type t, c;
+    for (int i = 0; i < N; i++) {
+      t.l[i] = v[i];
+      c.l[i] = (uint64_t)UP::C_OUT[2 * i] | ((uint64_t)UP::C_OUT[2 * i + 1] << 32);
+    }
+    return type::mul(t, c);
+  }
+};
+
+template <class F>
+static inline XYZZ<typename HostField<F>::type> xyzz_to_host(const XYZZ<F>& p) {
+  using H = HostField<F>;
+  return {H::conv(p.x), H::conv(p.y), H::conv(p.zz), H::conv(p.zzz)};
+}
 
 }  // namespace ctt

@@ -29,12 +29,14 @@ static constexpr uint32_t KEY_NONE = 0xffffffffu;
 // Curve descriptors (a = 0 everywhere; only the field, scalar field and scalar width matter for MSM)
 // constantine/named/config_fields_and_curves.nim:116-133,214-229,269-287
 // ---------------------------------------------------------------------------------------------
-struct Bls12381G1 { using F = Fp<BLS12_381_Fp>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 0; };
-struct Bls12381G2 { using F = Fp2<Fp<BLS12_381_Fp>>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 1; };
-struct Bn254G1 { using F = Fp<BN254_Fp>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; };
-struct Bn254G2 { using F = Fp2<Fp<BN254_Fp>>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 3; };
-struct PallasEc { using F = Fp<Pallas_Fp>; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; };
-struct VestaEc { using F = Fp<Vesta_Fp>; using Fr = Fp<Pallas_Fp>; static constexpr int BITS = 255; static constexpr int ID = 5; };
+// F  = coordinate field in the reference's representation (what the C API hands over and takes back)
+// FD = coordinate field the kernels compute in (carry-free limbs where that is faster, see fpu.h)
+struct Bls12381G1 { using F = Fp<BLS12_381_Fp>; using FD = FpU<BLS12_381_Fp_U>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 0; };
+struct Bls12381G2 { using F = Fp2<Fp<BLS12_381_Fp>>; using FD = F; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 1; };
+struct Bn254G1 { using F = Fp<BN254_Fp>; using FD = F; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; };
+struct Bn254G2 { using F = Fp2<Fp<BN254_Fp>>; using FD = F; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 3; };
+struct PallasEc { using F = Fp<Pallas_Fp>; using FD = F; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; };
+struct VestaEc { using F = Fp<Vesta_Fp>; using FD = F; using Fr = Fp<Pallas_Fp>; static constexpr int BITS = 255; static constexpr int ID = 5; };
 
 // ---------------------------------------------------------------------------------------------
 // Booth signed digits
@@ -85,6 +87,17 @@ CTT_HD void fr_from_mont_body(const uint32_t* in, uint32_t* out, uint32_t n, uin
   a = Fr::from_mont(a);
 #pragma unroll
   for (int i = 0; i < Fr::N; i++) out[(uint64_t)Fr::N * j + i] = a.l[i];
+}
+
+// Input points: reference representation -> device field (one pass per MSM; (0,0) stays (0,0))
+template <class F, class FD>
+CTT_HD void convert_point_body(const Affine<F>* in, Affine<FD>* out, uint32_t n, uint32_t j) {
+  if (j >= n) return;
+  Affine<F> p = in[j];
+  Affine<FD> q;
+  q.x = FD::from_sat(p.x);
+  q.y = FD::from_sat(p.y);
+  out[j] = q;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "host_fp64.h"
@@ -95,19 +96,22 @@ enum { ST_DIGITS = 0, ST_SORT, ST_ACCUM, ST_MERGE, ST_REDUCE, ST_TOTAL, ST_COUNT
 
 template <class C, class BK>
 struct MsmEngine {
-  using F = typename C::F;
+  using F = typename C::F;    // reference representation (C API)
+  using FD = typename C::FD;  // device representation
+  static constexpr bool kConvert = !std::is_same<F, FD>::value;
   BK& bk;
   MsmOptions opt;
   MsmPlan last_plan;
 
   // grow-only workspace
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf digits, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcount;
+  Buf digits, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcount, cpoints;
 
   explicit MsmEngine(BK& b) : bk(b) {}
   ~MsmEngine() {
-    Buf* all[] = {&digits, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount};
+    Buf* all[] = {&digits, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount, &cpoints};
     for (Buf* b : all) if (b->p) bk.free(b->p);
+    for (Slot& sl : slots) if (sl.hraw) bk.free_host(sl.hraw);
   }
   void* need(Buf& b, size_t bytes) {
     if (bytes > b.cap) {
@@ -119,31 +123,61 @@ struct MsmEngine {
     return b.p;
   }
 
+  // Two MSMs may be in flight: submit() enqueues every kernel of one MSM plus the asynchronous copy of its
+  // c points per window into a pinned host buffer; finish() waits for that copy and runs the host tail.
+  // Calling submit(i+1) before finish(i) overlaps the host tail of MSM i with the GPU work of MSM i+1
+  // (the workspace is shared: stream order keeps the two apart on the device).
+  using HF = typename HostField<FD>::type;
+  struct Slot {
+    MsmPlan plan;
+    bool busy = false;
+    bool empty = false;   // len == 0
+    void* hraw = nullptr; // pinned host buffer for the device output
+    size_t hcap = 0;
+  };
+  Slot slots[2];
+  int next_slot = 0;
+
   // d_coefs: canonical scalars [n][8] (coef_is_fr = false) or Montgomery Fr elements (true), device memory.
-  // d_points: affine Montgomery points, device memory.  Result: the MSM as an XYZZ point on the host
-  // (host arithmetic on 64-bit limbs, same memory layout as the device field).
-  using HF = typename HostField<F>::type;
-  XYZZ<HF> run(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points, uint32_t n) {
-    static_assert(sizeof(XYZZ<HF>) == sizeof(XYZZ<F>), "host/device layouts must match");
-    if (n == 0) return XYZZ<HF>::inf();  // len == 0 is UB upstream; we return the neutral
+  // d_points: affine Montgomery points (reference representation), device memory.  Returns the slot.
+  int submit(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n) {
+    const int sl = next_slot;
+    Slot& S = slots[sl];
+    if (S.busy) {
+      fprintf(stderr, "[ctt_msm] FATAL: more than two MSMs in flight on one engine (finish() the oldest first)\n");
+      abort();
+    }
+    next_slot ^= 1;
+    S.busy = true;
+    S.empty = (n == 0);  // len == 0 is UB upstream; we return the neutral
+    if (S.empty) return sl;
     MsmPlan p = make_plan(n, C::BITS, opt);
+    S.plan = p;
     last_plan = p;
     const uint32_t W = p.W, B = p.B;
 
-    bk.stage_begin(ST_TOTAL);
-    bk.stage_begin(ST_DIGITS);
+    bk.stage_begin(sl, ST_TOTAL);
+    bk.stage_begin(sl, ST_DIGITS);
     const uint32_t* d_scalars = d_coefs;
     if (coef_is_fr) {
       uint32_t* t = (uint32_t*)need(scal, (size_t)n * 32);
       bk.template launch_fr_from_mont<typename C::Fr>(d_coefs, t, n);
       d_scalars = t;
     }
+    const Affine<FD>* d_points;
+    if constexpr (kConvert) {
+      Affine<FD>* cp = (Affine<FD>*)need(cpoints, (size_t)n * sizeof(Affine<FD>));
+      bk.template launch_convert<F, FD>(d_points_in, cp, n);
+      d_points = cp;
+    } else {
+      d_points = d_points_in;
+    }
     uint32_t* d_digits = (uint32_t*)need(digits, (size_t)W * n * 4);
     DigitsArgs da{d_scalars, d_digits, n, p.c, (int)W};
     bk.launch_digits(da);
-    bk.stage_end(ST_DIGITS);
+    bk.stage_end(sl, ST_DIGITS);
 
-    bk.stage_begin(ST_SORT);
+    bk.stage_begin(sl, ST_SORT);
     uint32_t* d_counts = (uint32_t*)need(counts, (size_t)W * p.S * B * 4);
     uint32_t* d_bstart = (uint32_t*)need(bstart, (size_t)W * (B + 1) * 4);
     uint32_t* d_entries = (uint32_t*)need(entries, (size_t)W * n * 4);
@@ -151,43 +185,70 @@ struct MsmEngine {
     bk.memset0(d_maxcount, 4);
     bk.launch_sort(d_digits, d_counts, d_bstart, d_entries, d_maxcount, n, B, p.S, p.slice, W);
     bk.fetch_u32_async(d_maxcount);  // largest bucket: read back while the accumulation runs
-    bk.stage_end(ST_SORT);
+    bk.stage_end(sl, ST_SORT);
 
-    bk.stage_begin(ST_ACCUM);
-    XYZZ<F>* d_buckets = (XYZZ<F>*)need(buckets, (size_t)W * B * sizeof(XYZZ<F>));
-    bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<F>));
-    XYZZ<F>* d_heads = (XYZZ<F>*)need(heads, (size_t)W * p.G * sizeof(XYZZ<F>));
-    XYZZ<F>* d_tails = (XYZZ<F>*)need(tails, (size_t)W * p.G * sizeof(XYZZ<F>));
+    bk.stage_begin(sl, ST_ACCUM);
+    XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(buckets, (size_t)W * B * sizeof(XYZZ<FD>));
+    bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_heads = (XYZZ<FD>*)need(heads, (size_t)W * p.G * sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_tails = (XYZZ<FD>*)need(tails, (size_t)W * p.G * sizeof(XYZZ<FD>));
     uint32_t* d_hkey = (uint32_t*)need(hkey, (size_t)W * p.G * 4);
     uint32_t* d_tkey = (uint32_t*)need(tkey, (size_t)W * p.G * 4);
-    AccumArgs<F> aa{d_entries, d_bstart, d_points, d_buckets, d_heads, d_tails, d_hkey, d_tkey, n, B, p.K, p.G};
-    bk.template launch_accum<F>(aa, W);
-    bk.stage_end(ST_ACCUM);
+    AccumArgs<FD> aa{d_entries, d_bstart, d_points, d_buckets, d_heads, d_tails, d_hkey, d_tkey, n, B, p.K, p.G};
+    bk.template launch_accum<FD>(aa, W);
+    bk.stage_end(sl, ST_ACCUM);
 
-    bk.stage_begin(ST_MERGE);
-    MergeArgs<F> ma{d_bstart, d_buckets, d_heads, d_tails, d_hkey, d_tkey, d_maxcount, B, p.K, p.G};
-    bk.template launch_merge_tail<F>(ma, W);
+    bk.stage_begin(sl, ST_MERGE);
+    MergeArgs<FD> ma{d_bstart, d_buckets, d_heads, d_tails, d_hkey, d_tkey, d_maxcount, B, p.K, p.G};
+    bk.template launch_merge_tail<FD>(ma, W);
     // tree steps over the head chain of a bucket: a bucket of m entries spans at most floor((m-1)/K)+1 heads
     const uint32_t mc = bk.fetch_u32_wait();
     const uint32_t chain = mc ? (mc - 1) / p.K + 1 : 0;
-    for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<F>(ma, W, d);
-    bk.template launch_merge_final<F>(ma, W);
-    bk.stage_end(ST_MERGE);
+    for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<FD>(ma, W, d);
+    bk.template launch_merge_final<FD>(ma, W);
+    bk.stage_end(sl, ST_MERGE);
 
-    bk.stage_begin(ST_REDUCE);
-    XYZZ<F>* d_pyr = (XYZZ<F>*)need(rA[0], (size_t)W * B * sizeof(XYZZ<F>));
-    XYZZ<F>* d_q = (XYZZ<F>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<F>));
-    XYZZ<F>* d_out = (XYZZ<F>*)need(rP[0], (size_t)W * p.c * sizeof(XYZZ<F>));
+    bk.stage_begin(sl, ST_REDUCE);
+    XYZZ<FD>* d_pyr = (XYZZ<FD>*)need(rA[0], (size_t)W * B * sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_q = (XYZZ<FD>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_out = (XYZZ<FD>*)need(rP[0], (size_t)W * p.c * sizeof(XYZZ<FD>));
     for (int pass = 0; pass <= p.c - 2; pass++) {
-      PyrArgs<F> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass};
-      bk.template launch_pyr<F>(pa, W, pyr_pass_tasks(B, p.c, pass));
+      PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass};
+      bk.template launch_pyr<FD>(pa, W, pyr_pass_tasks(B, p.c, pass));
     }
-    bk.stage_end(ST_REDUCE);
+    bk.stage_end(sl, ST_REDUCE);
 
-    std::vector<XYZZ<HF>> sums((size_t)W * p.c);
-    bk.d2h(sums.data(), d_out, (size_t)W * p.c * sizeof(XYZZ<F>));  // synchronises
-    bk.stage_end(ST_TOTAL);
-    return combine_windows_bits<HF>(sums.data(), (int)W, p.c);
+    const size_t bytes = (size_t)W * p.c * sizeof(XYZZ<FD>);
+    if (bytes > S.hcap) {
+      if (S.hraw) bk.free_host(S.hraw);
+      S.hraw = bk.alloc_host(bytes);
+      S.hcap = bytes;
+    }
+    bk.d2h_async(sl, S.hraw, d_out, bytes);
+    bk.stage_end(sl, ST_TOTAL);
+    return sl;
+  }
+
+  // Host tail of a submitted MSM: wait for its device output, Horner over (window, bit).
+  XYZZ<HF> finish(int sl) {
+    Slot& S = slots[sl];
+    if (!S.busy) {
+      fprintf(stderr, "[ctt_msm] FATAL: finish() of a slot that was not submitted\n");
+      abort();
+    }
+    S.busy = false;
+    if (S.empty) return XYZZ<HF>::inf();
+    bk.d2h_wait(sl);
+    const MsmPlan& p = S.plan;
+    const XYZZ<FD>* raw = (const XYZZ<FD>*)S.hraw;
+    const size_t cnt = (size_t)p.W * p.c;
+    std::vector<XYZZ<HF>> sums(cnt);
+    for (size_t i = 0; i < cnt; i++) sums[i] = xyzz_to_host<FD>(raw[i]);
+    return combine_windows_bits<HF>(sums.data(), p.W, p.c);
+  }
+
+  XYZZ<HF> run(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n) {
+    return finish(submit(d_coefs, coef_is_fr, d_points_in, n));
   }
 };
 

@@ -97,6 +97,34 @@ class DeviceMsm:
             raise RuntimeError("ctt_hip_msm_device failed")
         return r
 
+    def submit(self, curve, d_coefs, d_points, n, fr_coefs=False):
+        """Enqueue one MSM and return a ticket at once (at most two outstanding per curve)."""
+        info = CURVES[curve]
+        t = self.L.ctt_hip_msm_device_submit(self.ctx, info.cid, COEF_FR if fr_coefs else COEF_BIG,
+                                             self._dptr(d_coefs), self._dptr(d_points), n)
+        if t < 0:
+            raise RuntimeError("ctt_hip_msm_device_submit failed")
+        return (curve, t)
+
+    def finish(self, ticket, coord="aff"):
+        """Wait for a submitted MSM, run the host tail, return the result."""
+        curve, t = ticket
+        info = CURVES[curve]
+        nco = 2 if coord == "aff" else 3
+        r = np.zeros(nco * info.coord_bytes, dtype=np.uint8)
+        if self.L.ctt_hip_msm_device_finish(self.ctx, t, _COORD[coord], _ptr(r)) != 0:
+            raise RuntimeError("ctt_hip_msm_device_finish failed")
+        return r
+
+    def sync(self):
+        """Wait until everything enqueued on the engine's stream has completed."""
+        import ctypes as _c
+        hip = _c.CDLL("libamdhip64.so")
+        hip.hipStreamSynchronize.argtypes = [_c.c_void_p]
+        rc = hip.hipStreamSynchronize(_c.c_void_p(self.L.ctt_hip_msm_stream(self.ctx)))
+        if rc != 0:
+            raise RuntimeError(f"hipStreamSynchronize failed: {rc}")
+
     def gen_points(self, curve, seed, n, d_out, first=0):
         rc = self.L.ctt_hip_gen_points(self.ctx, CURVES[curve].cid, seed & (2**64 - 1), first, n, self._dptr(d_out))
         if rc != 0:

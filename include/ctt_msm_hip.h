@@ -132,7 +132,14 @@ int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
  * Returns 0, or -1 for a bad curve id.  Blocks until r is written. */
 int ctt_hip_msm_device(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, int out_kind, void* r, const void* d_coefs,
                        const void* d_points, size_t len);
-/* HIP-event stage times (ms) of the last call: digits, sort, accumulate, merge, reduce, total. */
+/* Split form: submit enqueues the GPU work of one MSM and returns a ticket (>= 0, or -1 on bad arguments) at once;
+ * finish waits for it, runs the host tail (Horner over windows, affine normalisation) and writes r.  At most two
+ * tickets per curve may be outstanding; submitting MSM i+1 before finishing MSM i overlaps the host tail of i with
+ * the GPU work of i+1 (this is how bench.py keeps the GPU busy between steps). */
+int ctt_hip_msm_device_submit(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, const void* d_coefs, const void* d_points,
+                              size_t len);
+int ctt_hip_msm_device_finish(ctt_hip_msm_ctx* ctx, int ticket, int out_kind, void* r);
+/* HIP-event stage times (ms) of the last finished MSM: digits, sort, accumulate, merge, reduce, total. */
 int ctt_hip_msm_last_timings(ctt_hip_msm_ctx* ctx, float* ms, int cap);
 /* plan of the last call: c, W, K, G, S, resident lanes */
 int ctt_hip_msm_last_plan(ctt_hip_msm_ctx* ctx, int* out, int cap);

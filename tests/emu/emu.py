@@ -13,14 +13,9 @@ _lib = None
 
 
 def build():
-    src = os.path.join(HERE, "msm_emu.cpp")
-    out = os.path.join(HERE, "libmsm_emu.so")
-    inc = os.path.join(ROOT, "constantine_amd", "csrc")
-    deps = [src] + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
-        return out
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", inc, src, "-o", out])
-    return out
+    jobs = str(max(1, min(8, os.cpu_count() or 1)))
+    subprocess.check_call(["make", "-s", "-j", jobs, "-C", HERE])
+    return os.path.join(HERE, "libmsm_emu.so")
 
 
 def lib():
@@ -31,6 +26,8 @@ def lib():
         L.emu_msm.argtypes = [i32, i32, i32, vp, vp, vp, sz, i32, i32, i32, i32, vp]
         L.emu_gen_points.argtypes = [i32, u64, u64, u32, vp]
         L.emu_field_op.argtypes = [i32, i32, vp, vp, vp]
+        L.emu_field_op_dev.argtypes = [i32, i32, vp, vp, vp]
+        L.emu_dev_field_info.argtypes = [i32, vp, vp]
         _lib = L
     return _lib
 
@@ -63,3 +60,19 @@ def field_op(curve, op, a, b=None):
     out = np.zeros_like(a)
     lib().emu_field_op(CURVE_ID[curve], op, _p(a), _p(b), _p(out))
     return out
+
+
+def dev_field_info(curve):
+    """(limb_bits, limb_count) of the curve's device field when it is the carry-free one, else None."""
+    lb, nl = ctypes.c_int(0), ctypes.c_int(0)
+    ok = lib().emu_dev_field_info(CURVE_ID[curve], ctypes.byref(lb), ctypes.byref(nl))
+    return (lb.value, nl.value) if ok else None
+
+
+def field_op_dev(curve, op, a, b=None):
+    """Device-field probe: a, b in the reference representation; returns raw device limbs (uint32[NL])."""
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = a if b is None else np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.zeros(32, dtype=np.uint32)
+    nl = lib().emu_field_op_dev(CURVE_ID[curve], op, _p(a), _p(b), _p(out))
+    return out[:nl]

@@ -16,16 +16,23 @@ struct EmuBackend {
   void* alloc(size_t b) { return malloc(b); }
   void free(void* p) { ::free(p); }
   void memset0(void* p, size_t b) { memset(p, 0, b); }
-  void d2h(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
+  void* alloc_host(size_t b) { return malloc(b); }
+  void free_host(void* p) { ::free(p); }
+  void d2h_async(int, void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
+  void d2h_wait(int) {}
   uint32_t word = 0;
   void fetch_u32_async(const uint32_t* d) { word = *d; }
   uint32_t fetch_u32_wait() { return word; }
-  void stage_begin(int) {}
-  void stage_end(int) {}
+  void stage_begin(int, int) {}
+  void stage_end(int, int) {}
 
   template <class Fr>
   void launch_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
     for (uint32_t j = 0; j < n; j++) fr_from_mont_body<Fr>(in, out, n, j);
+  }
+  template <class F, class FD>
+  void launch_convert(const Affine<F>* in, Affine<FD>* out, uint32_t n) {
+    for (uint32_t j = 0; j < n; j++) convert_point_body<F, FD>(in, out, n, j);
   }
   void launch_digits(const DigitsArgs& a) {
     for (uint32_t j = 0; j < a.N; j++) digits_body(a, j);
@@ -94,84 +101,153 @@ struct EmuBackend {
   }
 };
 
-template <class C>
-static int emu_msm_t(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n,
-                     int c, int K, int rs_log, int S, int* plan_out) {
-  EmuBackend bk;
-  MsmEngine<C, EmuBackend> eng(bk);
-  eng.opt.c = c;
-  eng.opt.K = K;
-  if (rs_log > 0) eng.opt.rs_log = rs_log;
-  eng.opt.S = S;
-  eng.opt.lanes = 4096;
-  auto res = eng.run((const uint32_t*)coefs, coef_is_fr != 0, (const Affine<typename C::F>*)points, (uint32_t)n);
-  write_result<typename MsmEngine<C, EmuBackend>::HF>(r, res, out_kind);
-  if (plan_out && n) {
-    plan_out[0] = eng.last_plan.c; plan_out[1] = eng.last_plan.W; plan_out[2] = (int)eng.last_plan.K;
-    plan_out[3] = (int)eng.last_plan.G; plan_out[4] = (int)eng.last_plan.S;
-  }
-  return 0;
-}
+// ---------------------------------------------------------------------------------------------
+// Per-curve operation table.  This file is compiled once per curve (-DEMU_CURVE=<id>) and once without
+// (the dispatcher), so the build parallelises like the HIP library's.
+// ---------------------------------------------------------------------------------------------
+struct EmuOps {
+  int (*msm)(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c, int K,
+             int rs_log, int S, int* plan_out);
+  void (*gen)(uint64_t seed, uint64_t first, uint32_t n, void* out);
+  void (*fop)(int op, const void* a, const void* b, void* r);
+  int (*fop_dev)(int op, const void* a, const void* b, void* r);
+  int (*dev_info)(int* lb, int* nl);
+};
 
-template <class F>
-static void gen_t(const Affine<F>& G, uint64_t seed, uint64_t first, uint32_t n, void* out) {
-  for (uint32_t j = 0; j < n; j++) gen_point_body<F>(G, seed, first, n, (Affine<F>*)out, j);
-}
-
+#ifdef EMU_CURVE
 #include "generators.h"
 
-// field-level probes: op 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inv  (base field of the curve)
-template <class F>
-static void fop(int op, const void* a, const void* b, void* r) {
-  const F& x = *(const F*)a;
-  const F& y = *(const F*)b;
-  F& o = *(F*)r;
-  switch (op) {
-    case 0: o = F::mul(x, y); break;
-    case 1: o = F::sqr(x); break;
-    case 2: o = F::add(x, y); break;
-    case 3: o = F::sub(x, y); break;
-    case 4: o = F::neg(x); break;
-    case 5: o = F::inv(x); break;
+template <class C>
+struct EmuCurve {
+  using F = typename C::F;
+  using FD = typename C::FD;
+  static int msm(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c, int K,
+                 int rs_log, int S, int* plan_out) {
+    EmuBackend bk;
+    MsmEngine<C, EmuBackend> eng(bk);
+    eng.opt.c = c;
+    eng.opt.K = K;
+    if (rs_log > 0) eng.opt.rs_log = rs_log;
+    eng.opt.S = S;
+    eng.opt.lanes = 4096;
+    // exercise both in-flight slots: submit twice, finish in order
+    int s0 = eng.submit((const uint32_t*)coefs, coef_is_fr != 0, (const Affine<F>*)points, (uint32_t)n);
+    auto res = eng.finish(s0);
+    write_result<typename MsmEngine<C, EmuBackend>::HF>(r, res, out_kind);
+    if (plan_out && n) {
+      plan_out[0] = eng.last_plan.c; plan_out[1] = eng.last_plan.W; plan_out[2] = (int)eng.last_plan.K;
+      plan_out[3] = (int)eng.last_plan.G; plan_out[4] = (int)eng.last_plan.S;
+    }
+    return 0;
   }
-}
+  static void gen(uint64_t seed, uint64_t first, uint32_t n, void* out) {
+    Affine<F> G = generator<C>();
+    for (uint32_t j = 0; j < n; j++) gen_point_body<F>(G, seed, first, n, (Affine<F>*)out, j);
+  }
+  // field-level probes: op 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inv  (coordinate field, reference representation)
+  static void fop(int op, const void* a, const void* b, void* r) {
+    const F& x = *(const F*)a;
+    const F& y = *(const F*)b;
+    F& o = *(F*)r;
+    switch (op) {
+      case 0: o = F::mul(x, y); break;
+      case 1: o = F::sqr(x); break;
+      case 2: o = F::add(x, y); break;
+      case 3: o = F::sub(x, y); break;
+      case 4: o = F::neg(x); break;
+      case 5: o = F::inv(x); break;
+    }
+  }
+  // device-field probe: inputs in the reference representation, output raw FD limbs (uint32[NL]); returns NL
+  static int fop_dev(int op, const void* a, const void* b, void* r) {
+    if constexpr (FD::UNSAT) {
+      FD x = FD::from_sat(*(const F*)a), y = FD::from_sat(*(const F*)b), o;
+      switch (op) {
+        case 0: o = FD::mul(x, y); break;
+        case 1: o = FD::sqr(x); break;
+        case 2: o = FD::add(x, y); break;
+        case 3: o = FD::template sub<2>(x, y); break;
+        default: o = x; break;
+      }
+      *(FD*)r = o;
+      return FD::NL;
+    }
+    return 0;
+  }
+  static int dev_info(int* lb, int* nl) {
+    if constexpr (FD::UNSAT) {
+      *lb = FD::LB;
+      *nl = FD::NL;
+      return 1;
+    }
+    return 0;
+  }
+  static const EmuOps* ops() {
+    static const EmuOps o = {msm, gen, fop, fop_dev, dev_info};
+    return &o;
+  }
+};
+
+#if EMU_CURVE == 0
+extern "C" const EmuOps* emu_ops_0() { return EmuCurve<Bls12381G1>::ops(); }
+#elif EMU_CURVE == 1
+extern "C" const EmuOps* emu_ops_1() { return EmuCurve<Bls12381G2>::ops(); }
+#elif EMU_CURVE == 2
+extern "C" const EmuOps* emu_ops_2() { return EmuCurve<Bn254G1>::ops(); }
+#elif EMU_CURVE == 3
+extern "C" const EmuOps* emu_ops_3() { return EmuCurve<Bn254G2>::ops(); }
+#elif EMU_CURVE == 4
+extern "C" const EmuOps* emu_ops_4() { return EmuCurve<PallasEc>::ops(); }
+#elif EMU_CURVE == 5
+extern "C" const EmuOps* emu_ops_5() { return EmuCurve<VestaEc>::ops(); }
+#endif
+
+#else  // dispatcher
 
 extern "C" {
+const EmuOps* emu_ops_0();
+const EmuOps* emu_ops_1();
+const EmuOps* emu_ops_2();
+const EmuOps* emu_ops_3();
+const EmuOps* emu_ops_4();
+const EmuOps* emu_ops_5();
 
-int emu_msm(int curve, int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n,
-            int c, int K, int rs_log, int S, int* plan_out) {
+static const EmuOps* ops_of(int curve) {
   switch (curve) {
-    case 0: return emu_msm_t<Bls12381G1>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
-    case 1: return emu_msm_t<Bls12381G2>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
-    case 2: return emu_msm_t<Bn254G1>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
-    case 3: return emu_msm_t<Bn254G2>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
-    case 4: return emu_msm_t<PallasEc>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
-    case 5: return emu_msm_t<VestaEc>(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out);
+    case 0: return emu_ops_0();
+    case 1: return emu_ops_1();
+    case 2: return emu_ops_2();
+    case 3: return emu_ops_3();
+    case 4: return emu_ops_4();
+    case 5: return emu_ops_5();
   }
-  return -1;
+  return nullptr;
 }
 
+int emu_msm(int curve, int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c,
+            int K, int rs_log, int S, int* plan_out) {
+  const EmuOps* o = ops_of(curve);
+  return o ? o->msm(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out) : -1;
+}
 int emu_gen_points(int curve, uint64_t seed, uint64_t first, uint32_t n, void* out) {
-  switch (curve) {
-    case 0: gen_t(generator<Bls12381G1>(), seed, first, n, out); return 0;
-    case 1: gen_t(generator<Bls12381G2>(), seed, first, n, out); return 0;
-    case 2: gen_t(generator<Bn254G1>(), seed, first, n, out); return 0;
-    case 3: gen_t(generator<Bn254G2>(), seed, first, n, out); return 0;
-    case 4: gen_t(generator<PallasEc>(), seed, first, n, out); return 0;
-    case 5: gen_t(generator<VestaEc>(), seed, first, n, out); return 0;
-  }
-  return -1;
+  const EmuOps* o = ops_of(curve);
+  if (!o) return -1;
+  o->gen(seed, first, n, out);
+  return 0;
 }
-
 int emu_field_op(int curve, int op, const void* a, const void* b, void* r) {
-  switch (curve) {
-    case 0: fop<Bls12381G1::F>(op, a, b, r); return 0;
-    case 1: fop<Bls12381G2::F>(op, a, b, r); return 0;
-    case 2: fop<Bn254G1::F>(op, a, b, r); return 0;
-    case 3: fop<Bn254G2::F>(op, a, b, r); return 0;
-    case 4: fop<PallasEc::F>(op, a, b, r); return 0;
-    case 5: fop<VestaEc::F>(op, a, b, r); return 0;
-  }
-  return -1;
+  const EmuOps* o = ops_of(curve);
+  if (!o) return -1;
+  o->fop(op, a, b, r);
+  return 0;
+}
+int emu_field_op_dev(int curve, int op, const void* a, const void* b, void* r) {
+  const EmuOps* o = ops_of(curve);
+  return o ? o->fop_dev(op, a, b, r) : 0;
+}
+int emu_dev_field_info(int curve, int* lb, int* nl) {
+  const EmuOps* o = ops_of(curve);
+  return o ? o->dev_info(lb, nl) : 0;
 }
 }
+#endif

@@ -51,6 +51,40 @@ def test_field_ops_vs_python(name):
             assert F.from_mont_bytes(bytes(emu.field_op(name, 5, enc(a)))) == F.inv(a)
 
 
+@pytest.mark.parametrize("name", G1S)
+def test_carry_free_device_field_vs_python(name):
+    """fpu.h: values are x*R' mod p in LB-bit limbs, only bounded by a small multiple of p."""
+    info = emu.dev_field_info(name)
+    if info is None:
+        pytest.skip("curve computes in the canonical field")
+    lb, nl = info
+    curve = po.CURVES[name]
+    F = curve.F
+    p = F.p
+    Rp = 1 << (lb * nl)
+    rng = random.Random(9)
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 1 << (p.bit_length() - 1), F.R % p, Rp % p]
+
+    def enc(v):
+        return np.frombuffer(F.to_mont_bytes(v), dtype=np.uint8)
+
+    def dec(limbs):
+        assert all(int(x) < (1 << lb) for x in limbs[:-1]), "limbs must come back normalised"
+        v = sum(int(x) << (lb * i) for i, x in enumerate(limbs))
+        return v
+
+    for _ in range(200):
+        a = rng.choice(edge) if rng.random() < 0.2 else rng.randrange(p)
+        b = rng.choice(edge) if rng.random() < 0.2 else rng.randrange(p)
+        for op, want, bound in ((0, a * b % p, 2), (1, a * a % p, 2), (2, (a + b) % p, 4), (3, (a - b) % p, 4), (4, a, 2)):
+            v = dec(emu.field_op_dev(name, op, enc(a), enc(b)))
+            assert v < bound * p, (op, "bound")
+            assert v * pow(Rp, -1, p) % p == want, (name, op, a, b)
+    # raw zero in -> raw zero out (neutral flags rely on it)
+    assert not emu.field_op_dev(name, 4, enc(0)).any()
+    assert not emu.field_op_dev(name, 0, enc(0), enc(5)).any()
+
+
 @pytest.mark.parametrize("name", ALL)
 def test_gen_points_same_definition(name):
     a = emu.gen_points(name, 77, 5, first=2)

@@ -309,3 +309,20 @@ def test_pasta_and_g2_2pow20_properties(dev, torch_cuda):
     _full_size("pallas", 20, dev, torch_cuda, check_oracle=False)
     _full_size("vesta", 20, dev, torch_cuda, check_oracle=False)
     _full_size("bls12_381_g2", 18, dev, torch_cuda, check_oracle=False)
+
+
+def test_two_msms_in_flight(dev, torch_cuda):
+    """submit/finish split: results of pipelined MSMs (different sizes, shared workspace) are independent."""
+    torch = torch_cuda
+    name = "bls12_381_g1"
+    sizes = [3000, 70000, 1, 4096, 33333]
+    data = []
+    for i, n in enumerate(sizes):
+        pts = cref.gen_points(name, 700 + i, n)
+        sc = cref.synth_scalars(800 + i, n, 255)
+        data.append((n, _to_dev(torch, sc), _to_dev(torch, pts), bytes(cref.msm(name, sc, pts, nthreads=NT)[0])))
+    pending = dev.submit(name, data[0][1], data[0][2], data[0][0])
+    for i in range(len(data)):
+        nxt = dev.submit(name, data[i + 1][1], data[i + 1][2], data[i + 1][0]) if i + 1 < len(data) else None
+        assert bytes(dev.finish(pending, coord="aff")) == data[i][3], sizes[i]
+        pending = nxt
