@@ -49,7 +49,7 @@ CTT_HD XYZZ<F> xyzz_mdbl(const F& x, const F& y) {
   F Mm = F::add(F::dbl(xx), xx);                 // < 3M
   XYZZ<F> r;
   r.x = fsub<F, 2 * M>(F::sqr(Mm), F::dbl(S));   // < 3M
-  r.y = fsub<F, M>(F::mul(Mm, fsub<F, 3 * M>(S, r.x)), F::mul(W, y));  // < 2M
+  r.y = fmul_sub<F, M>(Mm, fsub<F, 3 * M>(S, r.x), y, W);  // Mm*(S-X3) - y*W, < 2M
   r.zz = V;
   r.zzz = W;
   return r;
@@ -67,7 +67,7 @@ CTT_HD_NOINLINE XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
   F Mm = F::add(F::dbl(xx), xx);                 // < 3M
   XYZZ<F> r;
   r.x = fsub<F, 2 * M>(F::sqr(Mm), F::dbl(S));   // < 3M
-  r.y = fsub<F, M>(F::mul(Mm, fsub<F, 3 * M>(S, r.x)), F::mul(W, p.y));  // < 2M
+  r.y = fmul_sub<F, 2 * M>(Mm, fsub<F, 3 * M>(S, r.x), p.y, W);  // Mm*(S-X3) - Y*W, < 2M
   r.zz = F::mul(V, p.zz);
   r.zzz = F::mul(W, p.zzz);
   return r;
@@ -106,7 +106,7 @@ CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
   F PPP = F::mul(P, PP);
   F Q = F::mul(acc.x, PP);
   F X3 = fsub<F, 2 * M>(fsub<F, M>(F::sqr(R), PPP), F::dbl(Q));        // < 4M
-  F Y3 = fsub<F, M>(F::mul(R, fsub<F, 4 * M>(Q, X3)), F::mul(acc.y, PPP));  // < 2M
+  F Y3 = fmul_sub<F, 2 * M>(R, fsub<F, 4 * M>(Q, X3), acc.y, PPP);     // R*(Q-X3) - Y1*PPP, < 2M
   acc.x = X3;
   acc.y = Y3;
   acc.zz = F::mul(acc.zz, PP);
@@ -140,7 +140,7 @@ CTT_HD_NOINLINE void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& q) {
   F PPP = F::mul(P, PP);
   F Q = F::mul(U1, PP);
   F X3 = fsub<F, 2 * M>(fsub<F, M>(F::sqr(R), PPP), F::dbl(Q));       // < 4M
-  F Y3 = fsub<F, M>(F::mul(R, fsub<F, 4 * M>(Q, X3)), F::mul(S1, PPP));   // < 2M
+  F Y3 = fmul_sub<F, M>(R, fsub<F, 4 * M>(Q, X3), S1, PPP);          // R*(Q-X3) - S1*PPP, < 2M
   acc.x = X3;
   acc.y = Y3;
   acc.zz = F::mul(F::mul(acc.zz, q.zz), PP);

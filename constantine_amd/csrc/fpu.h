@@ -81,23 +81,23 @@ struct FpU {
 #pragma unroll
     for (int k = 0; k < B; k++) maybe |= (l[0] == kp(k).l[0]);
     if (!maybe) return false;
+    return is_multiple_of_p(*this, B);
+  }
+  // rare path, kept out of line: compare against k*p limb by limb
+  static CTT_HD_NOINLINE bool is_multiple_of_p(FpU a, int B) {
     bool hit = false;
-#pragma unroll
     for (int k = 0; k < B; k++) {
-      constexpr_for_kp_cmp(k, hit);
+      uint32_t d = 0;
+      uint64_t c = 0;
+      for (int i = 0; i < NL; i++) {
+        uint64_t v = (uint64_t)UP::P[i] * (uint64_t)k + c;
+        uint32_t li = (i == NL - 1) ? (uint32_t)v : (uint32_t)(v & MASK);
+        c = v >> LB;
+        d |= a.l[i] ^ li;
+      }
+      hit |= (d == 0);
     }
     return hit;
-  }
-  CTT_HD void constexpr_for_kp_cmp(int k, bool& hit) const {
-    uint32_t d = 0;
-    uint64_t c = 0;
-    for (int i = 0; i < NL; i++) {  // rare path: recompute k*p limb by limb
-      uint64_t v = (uint64_t)UP::P[i] * (uint64_t)k + c;
-      uint32_t li = (i == NL - 1) ? (uint32_t)v : (uint32_t)(v & MASK);
-      c = v >> LB;
-      d |= l[i] ^ li;
-    }
-    hit |= (d == 0);
   }
 
   // carry propagation: limbs < 2^LB afterwards (the top limb keeps the excess)
@@ -178,6 +178,42 @@ struct FpU {
     return t;
   }
 
+  // (a*b + c*d)/R' (mod p): two products, one Montgomery reduction.  Needs a*b + c*d < R'*p.
+  CTT_HD static FpU mul2(const FpU& a, const FpU& b, const FpU& c, const FpU& d) {
+    uint64_t acc = 0;
+    uint32_t m[NL];
+    FpU t;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (uint64_t)a.l[i] * b.l[k - i];
+        acc += (uint64_t)c.l[i] * d.l[k - i];
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++)
+        if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
+      m[k] = ((uint32_t)acc * UP::M0INV) & MASK;
+      acc += (uint64_t)m[k] * UP::P[0];
+      acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; i++) {
+        acc += (uint64_t)a.l[i] * b.l[k - i];
+        acc += (uint64_t)c.l[i] * d.l[k - i];
+      }
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; i++)
+        if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
+      t.l[k - NL] = (uint32_t)acc & MASK;
+      acc >>= LB;
+    }
+    t.l[NL - 1] = (uint32_t)acc;
+    return t;
+  }
+
   // square: cross products once with a doubled operand (2*a_i < 2^31 fits)
   CTT_HD static FpU sqr(const FpU& a) {
     uint64_t acc = 0;
@@ -238,6 +274,15 @@ template <class F, int B> CTT_HD F fsub(const F& a, const F& b) {
 }
 template <class F, int B> CTT_HD F fcneg(const F& a, bool c) {
   if constexpr (F::UNSAT) return F::template cneg<B>(a, c); else return F::cneg(a, c);
+}
+// a*b - c*d with one reduction where the field supports it; B bounds d's partner c (c < B*p)
+template <class F, int B> CTT_HD F fmul_sub(const F& a, const F& b, const F& c, const F& d) {
+  if constexpr (F::UNSAT) {
+    F nc = F::template sub<B>(F::zero(), c);   // B*p - c  (< B*p), so a*b + nc*d == a*b - c*d (mod p)
+    return F::mul2(a, b, nc, d);
+  } else {
+    return F::sub(F::mul(a, b), F::mul(c, d));
+  }
 }
 template <class F, int B> CTT_HD bool fis_zero_modp(const F& a) {
   if constexpr (F::UNSAT) return a.template is_zero_modp<B>(); else return a.is_zero();

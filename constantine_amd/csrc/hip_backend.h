@@ -31,12 +31,15 @@ static constexpr int ACCUM_BLOCK = 64;
 static constexpr int EC_BLOCK = 64;
 
 template <class F, class FD>
-__global__ void k_convert_points(const Affine<F>* in, Affine<FD>* out, uint32_t n) {
+__global__ void k_convert_points(const Affine<F>* in, void* out, uint32_t n) {
   convert_point_body<F, FD>(in, out, n, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+#ifndef CTT_ACCUM_WAVES
+#define CTT_ACCUM_WAVES 2   // waves per SIMD the accumulate kernel is compiled for (register budget 512/waves)
+#endif
 template <class F>
-__global__ void __launch_bounds__(ACCUM_BLOCK) k_accum(AccumArgs<F> a) {
+__global__ void __launch_bounds__(ACCUM_BLOCK, CTT_ACCUM_WAVES) k_accum(AccumArgs<F> a) {
   accum_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
 }
 template <class F>
@@ -176,13 +179,13 @@ struct HipBackend {
     HIP_CHECK(hipGetLastError());
   }
   template <class F, class FD>
-  void launch_convert(const Affine<F>* in, Affine<FD>* out, uint32_t n) {
+  void launch_convert(const Affine<F>* in, void* out, uint32_t n) {
     hipLaunchKernelGGL((k_convert_points<F, FD>), grid1(n, 256), dim3(256), 0, stream, in, out, n);
     HIP_CHECK(hipGetLastError());
   }
   void launch_digits(const DigitsArgs& a);  // msm_engine.hip
-  void launch_sort(const uint32_t* digits, uint32_t* counts, uint32_t* bstart, uint32_t* entries, uint32_t* maxcount,
-                   uint32_t n, uint32_t B, uint32_t S, uint32_t slice, uint32_t W);  // msm_engine.hip
+  void launch_sort(const uint32_t* digits, uint32_t* counts, uint32_t* totals, uint32_t* bstart, uint32_t* entries,
+                   uint32_t* maxcount, uint32_t n, uint32_t B, uint32_t S, uint32_t slice, uint32_t W);  // msm_engine.hip
   template <class F>
   void launch_accum(const AccumArgs<F>& a, uint32_t W) {
     hipLaunchKernelGGL(k_accum<F>, grid2(a.G, ACCUM_BLOCK, W), dim3(ACCUM_BLOCK), 0, stream, a);

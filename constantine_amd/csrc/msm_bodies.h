@@ -33,10 +33,10 @@ static constexpr uint32_t KEY_NONE = 0xffffffffu;
 // FD = coordinate field the kernels compute in (carry-free limbs where that is faster, see fpu.h)
 struct Bls12381G1 { using F = Fp<BLS12_381_Fp>; using FD = FpU<BLS12_381_Fp_U>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 0; };
 struct Bls12381G2 { using F = Fp2<Fp<BLS12_381_Fp>>; using FD = F; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 1; };
-struct Bn254G1 { using F = Fp<BN254_Fp>; using FD = F; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; };
+struct Bn254G1 { using F = Fp<BN254_Fp>; using FD = FpU<BN254_Fp_U>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; };
 struct Bn254G2 { using F = Fp2<Fp<BN254_Fp>>; using FD = F; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 3; };
-struct PallasEc { using F = Fp<Pallas_Fp>; using FD = F; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; };
-struct VestaEc { using F = Fp<Vesta_Fp>; using FD = F; using Fr = Fp<Pallas_Fp>; static constexpr int BITS = 255; static constexpr int ID = 5; };
+struct PallasEc { using F = Fp<Pallas_Fp>; using FD = FpU<Pallas_Fp_U>; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; };
+struct VestaEc { using F = Fp<Vesta_Fp>; using FD = FpU<Vesta_Fp_U>; using Fr = Fp<Pallas_Fp>; static constexpr int BITS = 255; static constexpr int ID = 5; };
 
 // ---------------------------------------------------------------------------------------------
 // Booth signed digits
@@ -89,15 +89,20 @@ CTT_HD void fr_from_mont_body(const uint32_t* in, uint32_t* out, uint32_t n, uin
   for (int i = 0; i < Fr::N; i++) out[(uint64_t)Fr::N * j + i] = a.l[i];
 }
 
+// Converted points are stored one per 128-byte line: after the sort every lane gathers whole points by index,
+// and a 112-byte (or 72-byte) record at its natural stride would straddle two cache lines most of the time.
+static constexpr uint32_t GATHER_STRIDE = 128;
+
 // Input points: reference representation -> device field (one pass per MSM; (0,0) stays (0,0))
 template <class F, class FD>
-CTT_HD void convert_point_body(const Affine<F>* in, Affine<FD>* out, uint32_t n, uint32_t j) {
+CTT_HD void convert_point_body(const Affine<F>* in, void* out, uint32_t n, uint32_t j) {
+  static_assert(sizeof(Affine<FD>) <= GATHER_STRIDE, "record must fit one line");
   if (j >= n) return;
   Affine<F> p = in[j];
   Affine<FD> q;
   q.x = FD::from_sat(p.x);
   q.y = FD::from_sat(p.y);
-  out[j] = q;
+  *(Affine<FD>*)((char*)out + (uint64_t)j * GATHER_STRIDE) = q;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -107,7 +112,8 @@ template <class F>
 struct AccumArgs {
   const uint32_t* entries;       // [W][N]   idx | sign<<31, sorted by bucket within a window
   const uint32_t* bucket_start;  // [W][B+1] exclusive prefix of bucket sizes; [B] = entries in window
-  const Affine<F>* points;
+  const void* points;            // affine points, `point_stride` bytes apart
+  uint32_t point_stride;
   XYZZ<F>* buckets;              // [W][B]   (pre-zeroed = neutral)
   XYZZ<F>* heads;                // [W][G]
   XYZZ<F>* tails;                // [W][G]
@@ -158,7 +164,9 @@ CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
       bend = bs[b + 1];
     }
     uint32_t e = ent[pos];
-    Affine<F> pt = a.points[e & 0x7fffffffu];
+    const Affine<F>* pp = (const Affine<F>*)__builtin_assume_aligned(
+        (const char*)a.points + (uint64_t)(e & 0x7fffffffu) * a.point_stride, 16);
+    Affine<F> pt = *pp;
     xyzz_madd<F>(acc, pt, (e >> 31) != 0);
   }
   const bool started_before = first_run && bs[b] < p0;

@@ -55,8 +55,8 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   if (p.c > 16) p.c = 16;
   p.W = bits / p.c + 1;  // ec_multi_scalar_mul_parallel.nim:157-158: one more window when c | bits
   p.B = 1u << (p.c - 1);
-  // sort slices: aim at >= 256 workgroups, slices of at least 4096 scalars
-  uint32_t S = o.S > 0 ? (uint32_t)o.S : (256u + p.W - 1) / p.W;
+  // sort slices: 32 per window (one window occupies the 32 CUs of one XCD), slices of at least 4096 scalars
+  uint32_t S = o.S > 0 ? (uint32_t)o.S : 32u;
   uint32_t maxS = (n + 4095u) / 4096u;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -105,11 +105,11 @@ struct MsmEngine {
 
   // grow-only workspace
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf digits, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcount, cpoints;
+  Buf digits, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcount, cpoints, totals;
 
   explicit MsmEngine(BK& b) : bk(b) {}
   ~MsmEngine() {
-    Buf* all[] = {&digits, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount, &cpoints};
+    Buf* all[] = {&digits, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount, &cpoints, &totals};
     for (Buf* b : all) if (b->p) bk.free(b->p);
     for (Slot& sl : slots) if (sl.hraw) bk.free_host(sl.hraw);
   }
@@ -164,13 +164,16 @@ struct MsmEngine {
       bk.template launch_fr_from_mont<typename C::Fr>(d_coefs, t, n);
       d_scalars = t;
     }
-    const Affine<FD>* d_points;
+    const void* d_points;
+    uint32_t point_stride;
     if constexpr (kConvert) {
-      Affine<FD>* cp = (Affine<FD>*)need(cpoints, (size_t)n * sizeof(Affine<FD>));
+      void* cp = need(cpoints, (size_t)n * GATHER_STRIDE);
       bk.template launch_convert<F, FD>(d_points_in, cp, n);
       d_points = cp;
+      point_stride = GATHER_STRIDE;
     } else {
       d_points = d_points_in;
+      point_stride = (uint32_t)sizeof(Affine<F>);
     }
     uint32_t* d_digits = (uint32_t*)need(digits, (size_t)W * n * 4);
     DigitsArgs da{d_scalars, d_digits, n, p.c, (int)W};
@@ -183,7 +186,8 @@ struct MsmEngine {
     uint32_t* d_entries = (uint32_t*)need(entries, (size_t)W * n * 4);
     uint32_t* d_maxcount = (uint32_t*)need(maxcount, 256);
     bk.memset0(d_maxcount, 4);
-    bk.launch_sort(d_digits, d_counts, d_bstart, d_entries, d_maxcount, n, B, p.S, p.slice, W);
+    uint32_t* d_totals = (uint32_t*)need(totals, (size_t)W * B * 4);
+    bk.launch_sort(d_digits, d_counts, d_totals, d_bstart, d_entries, d_maxcount, n, B, p.S, p.slice, W);
     bk.fetch_u32_async(d_maxcount);  // largest bucket: read back while the accumulation runs
     bk.stage_end(sl, ST_SORT);
 
@@ -194,7 +198,7 @@ struct MsmEngine {
     XYZZ<FD>* d_tails = (XYZZ<FD>*)need(tails, (size_t)W * p.G * sizeof(XYZZ<FD>));
     uint32_t* d_hkey = (uint32_t*)need(hkey, (size_t)W * p.G * 4);
     uint32_t* d_tkey = (uint32_t*)need(tkey, (size_t)W * p.G * 4);
-    AccumArgs<FD> aa{d_entries, d_bstart, d_points, d_buckets, d_heads, d_tails, d_hkey, d_tkey, n, B, p.K, p.G};
+    AccumArgs<FD> aa{d_entries, d_bstart, d_points, point_stride, d_buckets, d_heads, d_tails, d_hkey, d_tkey, n, B, p.K, p.G};
     bk.template launch_accum<FD>(aa, W);
     bk.stage_end(sl, ST_ACCUM);
 

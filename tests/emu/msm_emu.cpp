@@ -31,14 +31,14 @@ struct EmuBackend {
     for (uint32_t j = 0; j < n; j++) fr_from_mont_body<Fr>(in, out, n, j);
   }
   template <class F, class FD>
-  void launch_convert(const Affine<F>* in, Affine<FD>* out, uint32_t n) {
+  void launch_convert(const Affine<F>* in, void* out, uint32_t n) {
     for (uint32_t j = 0; j < n; j++) convert_point_body<F, FD>(in, out, n, j);
   }
   void launch_digits(const DigitsArgs& a) {
     for (uint32_t j = 0; j < a.N; j++) digits_body(a, j);
   }
-  void launch_sort(const uint32_t* digits, uint32_t* counts, uint32_t* bstart, uint32_t* entries, uint32_t* maxcount,
-                   uint32_t n, uint32_t B, uint32_t S, uint32_t slice, uint32_t W) {
+  void launch_sort(const uint32_t* digits, uint32_t* counts, uint32_t* /*totals*/, uint32_t* bstart, uint32_t* entries,
+                   uint32_t* maxcount, uint32_t n, uint32_t B, uint32_t S, uint32_t slice, uint32_t W) {
     for (uint32_t w = 0; w < W; w++) {
       // hist
       for (uint32_t s = 0; s < S; s++) {
