@@ -30,6 +30,24 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 BYTES_PER_PAIR = {"bls12_381_g1": 128, "bn254_snarks_g1": 96, "pallas": 96, "vesta": 96, "bls12_381_g2": 224}
 
 
+def host_cpu_budget():
+    """CPUs this process may actually use: min(affinity, cgroup quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(int(q) / int(per)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / per))))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -37,7 +55,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--curve", default="bls12_381_g1")
     ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n")
-    ap.add_argument("--cpu-sample-log2", type=int, default=17, help="pairs timed on the CPU baseline")
+    ap.add_argument("--cpu-sample-log2", type=int, default=20, help="pairs timed on the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -161,7 +179,8 @@ def main():
         # ---- CPU baseline: the oracle port on the host cores, bounded sample; doubles as a parity check -----
         if world == 1 and not args.no_cpu_baseline:
             m = min(n, 1 << args.cpu_sample_log2)
-            cores = os.cpu_count() or 1
+            budget = host_cpu_budget()           # the GPU box caps the container at a CPU quota
+            cores = min(os.cpu_count() or 1, 2 * budget)  # 2 threads per granted CPU balances the window tasks best
             pts_host = d_points[:m].cpu().numpy()
             t1 = time.perf_counter()
             exp, c_used = cref.msm(curve, scal[:m], pts_host, nthreads=cores)
@@ -170,7 +189,8 @@ def main():
             out["cpu_baseline"] = {
                 "value": m / cpu_dt, "unit": "points/s", "cores": cores, "kind": "port",
                 "sample": f"first 2^{int(np.log2(m))} pairs of the same workload, oracle/msm_ref.cpp "
-                          f"(restatement of Constantine's Pippenger, not Constantine), c={c_used}, {cpu_dt:.2f} s",
+                          f"(restatement of Constantine's Pippenger, not Constantine), c={c_used}, {cpu_dt:.2f} s wall, "
+                          f"{cores} threads on a {budget}-CPU cgroup quota ({os.cpu_count()} logical CPUs visible)",
             }
             out["parity_vs_oracle_on_sample"] = bool(bytes(got) == bytes(exp))
         print(json.dumps(out), flush=True)

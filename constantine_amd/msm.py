@@ -117,13 +117,8 @@ class DeviceMsm:
         return r
 
     def sync(self):
-        """Wait until everything enqueued on the engine's stream has completed."""
-        import ctypes as _c
-        hip = _c.CDLL("libamdhip64.so")
-        hip.hipStreamSynchronize.argtypes = [_c.c_void_p]
-        rc = hip.hipStreamSynchronize(_c.c_void_p(self.L.ctt_hip_msm_stream(self.ctx)))
-        if rc != 0:
-            raise RuntimeError(f"hipStreamSynchronize failed: {rc}")
+        """Wait until everything enqueued on the engine's stream(s) has completed."""
+        self.L.ctt_hip_msm_sync(self.ctx)
 
     def gen_points(self, curve, seed, n, d_out, first=0):
         rc = self.L.ctt_hip_gen_points(self.ctx, CURVES[curve].cid, seed & (2**64 - 1), first, n, self._dptr(d_out))

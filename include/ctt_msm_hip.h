@@ -125,7 +125,7 @@ int ctt_hip_msm_abi_version(void);
  * context on device $CTT_HIP_DEVICE (default 0). */
 ctt_hip_msm_ctx* ctt_hip_msm_ctx_create(int device);
 void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
-/* key in {"c","K","rs_log","S"}; value 0 = automatic. Returns 0, or -1 for an unknown key. */
+/* key in {"c","K","rs_log","S","lanes"}; value 0 = automatic ("lanes": 1 or 2 streams for submit). Returns 0, or -1 for an unknown key. */
 int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
 /* r (HOST memory, `out_kind` layout) = sum coefs[i] * points[i]; d_coefs / d_points are DEVICE pointers
  * (BigInt canonical or Fr Montgomery 32-byte scalars; affine Montgomery points, C-API struct layout).
@@ -139,6 +139,9 @@ int ctt_hip_msm_device(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, int out_k
 int ctt_hip_msm_device_submit(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, const void* d_coefs, const void* d_points,
                               size_t len);
 int ctt_hip_msm_device_finish(ctt_hip_msm_ctx* ctx, int ticket, int out_kind, void* r);
+/* Wait for everything enqueued on the context's stream(s) (successive submits alternate between two streams so
+ * that the latency-bound tail of one MSM overlaps the next MSM's sort and accumulation). */
+void ctt_hip_msm_sync(ctt_hip_msm_ctx* ctx);
 /* HIP-event stage times (ms) of the last finished MSM: digits, sort, accumulate, merge, reduce, total. */
 int ctt_hip_msm_last_timings(ctt_hip_msm_ctx* ctx, float* ms, int cap);
 /* plan of the last call: c, W, K, G, S, resident lanes */

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 ALL = list(po.CURVES)
 G1S = ["bls12_381_g1", "bn254_snarks_g1", "pallas", "vesta"]
-NT = max(1, (os.cpu_count() or 1))
+NT = max(1, min(32, os.cpu_count() or 1))  # the GPU box grants a 16-CPU quota
 
 
 @pytest.fixture(scope="module")
@@ -311,9 +311,12 @@ def test_pasta_and_g2_2pow20_properties(dev, torch_cuda):
     _full_size("bls12_381_g2", 18, dev, torch_cuda, check_oracle=False)
 
 
-def test_two_msms_in_flight(dev, torch_cuda):
-    """submit/finish split: results of pipelined MSMs (different sizes, shared workspace) are independent."""
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_two_msms_in_flight(dev, torch_cuda, lanes):
+    """submit/finish split: results of pipelined MSMs (different sizes, shared workspace) are independent;
+    lanes = 2 alternates successive submits between two streams/workspaces."""
     torch = torch_cuda
+    dev.set_option("lanes", lanes)
     name = "bls12_381_g1"
     sizes = [3000, 70000, 1, 4096, 33333]
     data = []
@@ -326,3 +329,4 @@ def test_two_msms_in_flight(dev, torch_cuda):
         nxt = dev.submit(name, data[i + 1][1], data[i + 1][2], data[i + 1][0]) if i + 1 < len(data) else None
         assert bytes(dev.finish(pending, coord="aff")) == data[i][3], sizes[i]
         pending = nxt
+    dev.set_option("lanes", 1)
