@@ -42,10 +42,9 @@ template <class F>
 CTT_HD XYZZ<F> xyzz_mdbl(const F& x, const F& y) {
   constexpr int M = F::MULB;
   F U = F::dbl(y);                               // < 2M
-  F V = F::sqr(U);                               // < M
-  F W = F::mul(U, V);
-  F S = F::mul(x, V);
-  F xx = F::sqr(x);
+  F V, xx, W, S;
+  fsqr_pair<F>(U, x, V, xx);                     // V = U^2, xx = x^2   (< M)
+  fmul_pair<F>(U, V, x, V, W, S);                // W = U*V, S = x*V
   F Mm = F::add(F::dbl(xx), xx);                 // < 3M
   XYZZ<F> r;
   r.x = fsub<F, 2 * M>(F::sqr(Mm), F::dbl(S));   // < 3M
@@ -60,16 +59,14 @@ CTT_HD_NOINLINE XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
   constexpr int M = F::MULB;
   if (p.is_inf()) return p;
   F U = F::dbl(p.y);                             // < 4M
-  F V = F::sqr(U);
-  F W = F::mul(U, V);
-  F S = F::mul(p.x, V);
-  F xx = F::sqr(p.x);
+  F V, xx, W, S;
+  fsqr_pair<F>(U, p.x, V, xx);                   // V = U^2, xx = X^2
+  fmul_pair<F>(U, V, p.x, V, W, S);              // W = U*V, S = X*V
   F Mm = F::add(F::dbl(xx), xx);                 // < 3M
   XYZZ<F> r;
   r.x = fsub<F, 2 * M>(F::sqr(Mm), F::dbl(S));   // < 3M
   r.y = fmul_sub<F, 2 * M>(Mm, fsub<F, 3 * M>(S, r.x), p.y, W);  // Mm*(S-X3) - Y*W, < 2M
-  r.zz = F::mul(V, p.zz);
-  r.zzz = F::mul(W, p.zzz);
+  fmul_pair<F>(V, p.zz, W, p.zzz, r.zz, r.zzz);
   return r;
 }
 
@@ -94,57 +91,57 @@ CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
     acc.zzz = F::one();
     return;
   }
-  F U2 = F::mul(q.x, acc.zz);                    // < M
-  F S2 = F::mul(qy, acc.zzz);
+  F U2, S2;
+  fmul_pair<F>(q.x, acc.zz, qy, acc.zzz, U2, S2);  // < M
   F P = fsub<F, 4 * M>(U2, acc.x);               // < 5M
   F R = fsub<F, 2 * M>(S2, acc.y);               // < 3M
   if (fis_zero_modp<F, 5 * M>(P)) {              // P == +-Q: rare, out of line
     acc = xyzz_madd_same_x<F>(q.x, qy, fis_zero_modp<F, 3 * M>(R));
     return;
   }
-  F PP = F::sqr(P);
-  F PPP = F::mul(P, PP);
-  F Q = F::mul(acc.x, PP);
-  F X3 = fsub<F, 2 * M>(fsub<F, M>(F::sqr(R), PPP), F::dbl(Q));        // < 4M
+  F PP, RR, PPP, Q;
+  fsqr_pair<F>(P, R, PP, RR);
+  fmul_pair<F>(P, PP, acc.x, PP, PPP, Q);
+  F X3 = fsub<F, 2 * M>(fsub<F, M>(RR, PPP), F::dbl(Q));               // < 4M
   F Y3 = fmul_sub<F, 2 * M>(R, fsub<F, 4 * M>(Q, X3), acc.y, PPP);     // R*(Q-X3) - Y1*PPP, < 2M
   acc.x = X3;
   acc.y = Y3;
-  acc.zz = F::mul(acc.zz, PP);
-  acc.zzz = F::mul(acc.zzz, PPP);
+  F Z2, Z3;
+  fmul_pair<F>(acc.zz, PP, acc.zzz, PPP, Z2, Z3);
+  acc.zz = Z2;
+  acc.zzz = Z3;
 }
 
-// acc += q, both XYZZ  (not on the hot path: kept out of line to bound code size / compile time)
+// acc += q, both XYZZ; returns by value so that neither operand has its address taken
 template <class F>
-CTT_HD_NOINLINE void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& q) {
+CTT_HD XYZZ<F> xyzz_add_inl(const XYZZ<F>& a, const XYZZ<F>& q) {
   constexpr int M = F::MULB;
-  if (q.is_inf()) return;
-  if (acc.is_inf()) {
-    acc = q;
-    return;
-  }
-  F U1 = F::mul(acc.x, q.zz);
-  F U2 = F::mul(q.x, acc.zz);
-  F S1 = F::mul(acc.y, q.zzz);
-  F S2 = F::mul(q.y, acc.zzz);
+  if (q.is_inf()) return a;
+  if (a.is_inf()) return q;
+  F U1, U2, S1, S2;
+  fmul_pair<F>(a.x, q.zz, q.x, a.zz, U1, U2);
+  fmul_pair<F>(a.y, q.zzz, q.y, a.zzz, S1, S2);
   F P = fsub<F, M>(U2, U1);                      // < 2M
   F R = fsub<F, M>(S2, S1);                      // < 2M
   if (fis_zero_modp<F, 2 * M>(P)) {
-    if (fis_zero_modp<F, 2 * M>(R)) {
-      acc = xyzz_dbl<F>(acc);
-    } else {
-      acc = XYZZ<F>::inf();
-    }
-    return;
+    if (fis_zero_modp<F, 2 * M>(R)) return xyzz_dbl<F>(a);
+    return XYZZ<F>::inf();
   }
-  F PP = F::sqr(P);
-  F PPP = F::mul(P, PP);
-  F Q = F::mul(U1, PP);
-  F X3 = fsub<F, 2 * M>(fsub<F, M>(F::sqr(R), PPP), F::dbl(Q));       // < 4M
-  F Y3 = fmul_sub<F, M>(R, fsub<F, 4 * M>(Q, X3), S1, PPP);          // R*(Q-X3) - S1*PPP, < 2M
-  acc.x = X3;
-  acc.y = Y3;
-  acc.zz = F::mul(F::mul(acc.zz, q.zz), PP);
-  acc.zzz = F::mul(F::mul(acc.zzz, q.zzz), PPP);
+  F PP, RR, PPP, Q, Z2, Z3;
+  fsqr_pair<F>(P, R, PP, RR);
+  fmul_pair<F>(P, PP, U1, PP, PPP, Q);
+  XYZZ<F> r;
+  r.x = fsub<F, 2 * M>(fsub<F, M>(RR, PPP), F::dbl(Q));               // < 4M
+  r.y = fmul_sub<F, M>(R, fsub<F, 4 * M>(Q, r.x), S1, PPP);          // R*(Q-X3) - S1*PPP, < 2M
+  fmul_pair<F>(a.zz, q.zz, a.zzz, q.zzz, Z2, Z3);
+  fmul_pair<F>(Z2, PP, Z3, PPP, r.zz, r.zzz);
+  return r;
+}
+
+// out-of-line form for call sites off the hot path (bounds code size / compile time)
+template <class F>
+CTT_HD_NOINLINE void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& q) {
+  acc = xyzz_add_inl<F>(acc, q);
 }
 
 // x = X/ZZ, y = Y/ZZZ (fromJacobianExtended_vartime, jacobian_extended.nim:353-379, then affine).

@@ -207,8 +207,7 @@ CTT_HD void merge_tail_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
   if (a.tkey[slot] == KEY_NONE) return;
   XYZZ<F> h = a.heads[slot + 1];
   XYZZ<F> t = a.tails[slot];
-  xyzz_add<F>(h, t);
-  a.heads[slot + 1] = h;
+  a.heads[slot + 1] = xyzz_add_inl<F>(h, t);
 }
 
 // tree step over the chain of heads of one bucket: heads[g] += heads[g+d] for g-chain_start = 0 mod 2d
@@ -345,7 +344,7 @@ CTT_HD void pyr_body(const PyrArgs<F>& a, uint32_t w, uint32_t t) {
   XYZZ<F> x = *s1;
   if (s2) {
     XYZZ<F> y = *s2;
-    xyzz_add<F>(x, y);
+    x = xyzz_add_inl<F>(x, y);
   }
   *d1 = x;
   if (d2) *d2 = x;
