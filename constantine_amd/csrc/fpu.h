@@ -369,6 +369,68 @@ struct FpU {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Fp2 = Fp[i]/(i^2+1) over the carry-free base field.  Every component is normalised and bounded like a base
+// element (MULB = 2: products come out of ONE Montgomery reduction each, < 2p):
+//   mul:  c0 = a0*b0 + (Kp - a1)*b1,  c1 = a0*b1 + a1*b0        (two sum-of-products, towers.nim:852-878 prod2x)
+//   sqr:  c0 = (a0 + a1)*(a0 - a1 + Kp),  c1 = a0*a1 + a0*a1    (square_complex, towers.nim:758-796)
+// K = 10 covers every operand the EC formulas produce (components < 5*MULB*p); needs 2*K^2 < R'/p, true for
+// BLS12-381 (R'/p = 2^11), not for the 29x9 fields.
+// ---------------------------------------------------------------------------------------------
+template <class UP>
+struct Fp2<FpU<UP>> {
+  using F = FpU<UP>;
+  using Base = F;
+  static constexpr int MULB = 2;
+  static constexpr bool UNSAT = true;
+  static constexpr int KNEG = 10;
+  static constexpr int LB = F::LB;
+  static constexpr int NL = 2 * F::NL;   // limbs of the whole element (c0 then c1)
+  static_assert(2 * KNEG * KNEG < (1 << UP::RP_OVER_P_LOG2), "Fp2 over this base field needs more Montgomery headroom");
+  F c0, c1;
+
+  CTT_HD static Fp2 zero() { return {F::zero(), F::zero()}; }
+  CTT_HD static Fp2 one() { return {F::one(), F::zero()}; }
+  CTT_HD bool is_zero() const { return c0.is_zero() & c1.is_zero(); }
+  template <int B>
+  CTT_HD bool is_zero_modp() const {
+    return c0.template is_zero_modp<B>() && c1.template is_zero_modp<B>();
+  }
+  CTT_HD static Fp2 select(bool c, const Fp2& a, const Fp2& b) {
+    return {F::select(c, a.c0, b.c0), F::select(c, a.c1, b.c1)};
+  }
+  CTT_HD static Fp2 add(const Fp2& a, const Fp2& b) { return {F::add(a.c0, b.c0), F::add(a.c1, b.c1)}; }
+  CTT_HD static Fp2 dbl(const Fp2& a) { return {F::dbl(a.c0), F::dbl(a.c1)}; }
+  template <int B>
+  CTT_HD static Fp2 sub(const Fp2& a, const Fp2& b) {
+    return {F::template sub<B>(a.c0, b.c0), F::template sub<B>(a.c1, b.c1)};
+  }
+  template <int B>
+  CTT_HD static Fp2 cneg(const Fp2& a, bool c) {
+    return {F::template cneg<B>(a.c0, c), F::template cneg<B>(a.c1, c)};
+  }
+  CTT_HD static Fp2 mul(const Fp2& a, const Fp2& b) {
+    F na1 = F::template sub<KNEG>(F::zero(), a.c1);
+    return {F::mul2(a.c0, b.c0, na1, b.c1), F::mul2(a.c0, b.c1, a.c1, b.c0)};
+  }
+  CTT_HD static Fp2 sqr(const Fp2& a) {
+    F s = F::add(a.c0, a.c1);
+    F d = F::template sub<KNEG>(a.c0, a.c1);
+    return {F::mul(s, d), F::mul2(a.c0, a.c1, a.c0, a.c1)};
+  }
+  // a*b + c*d: two products (not fused further: four base sum-of-products)
+  CTT_HD static Fp2 mul2(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return add(mul(a, b), mul(c, d)); }
+  CTT_HD static void mul_pair(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d, Fp2& r1, Fp2& r2) {
+    r1 = mul(a, b);
+    r2 = mul(c, d);
+  }
+  CTT_HD static void sqr_pair(const Fp2& a, const Fp2& c, Fp2& r1, Fp2& r2) {
+    r1 = sqr(a);
+    r2 = sqr(c);
+  }
+  CTT_HD static Fp2 from_sat(const Fp2<typename F::Sat>& s) { return {F::from_sat(s.c0), F::from_sat(s.c1)}; }
+};
+
 // Field-generic spellings used by ec.h: saturated fields ignore the bias/bound parameters.
 template <class F, int B> CTT_HD F fsub(const F& a, const F& b) {
   if constexpr (F::UNSAT) return F::template sub<B>(a, b); else return F::sub(a, b);
@@ -377,8 +439,12 @@ template <class F, int B> CTT_HD F fcneg(const F& a, bool c) {
   if constexpr (F::UNSAT) return F::template cneg<B>(a, c); else return F::cneg(a, c);
 }
 // a*b - c*d with one reduction where the field supports it; B bounds d's partner c (c < B*p)
+template <class F> struct IsFp2 { static constexpr bool value = false; };
+template <class B> struct IsFp2<Fp2<B>> { static constexpr bool value = true; };
 template <class F, int B> CTT_HD F fmul_sub(const F& a, const F& b, const F& c, const F& d) {
-  if constexpr (F::UNSAT) {
+  if constexpr (F::UNSAT && IsFp2<F>::value) {
+    return F::template sub<F::MULB>(F::mul(a, b), F::mul(c, d));   // < 2*MULB*p, the bound the callers assume
+  } else if constexpr (F::UNSAT) {
     F nc = F::template sub<B>(F::zero(), c);   // B*p - c  (< B*p), so a*b + nc*d == a*b - c*d (mod p)
     return F::mul2(a, b, nc, d);
   } else {

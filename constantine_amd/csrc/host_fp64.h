@@ -185,6 +185,11 @@ template <class UP> struct HostField<FpU<UP>> {
   }
 };
 
+template <class UP> struct HostField<Fp2<FpU<UP>>> {
+  using type = Fp2<Fp64<typename UP::Sat>>;
+  static inline type conv(const Fp2<FpU<UP>>& a) { return {HostField<FpU<UP>>::conv(a.c0), HostField<FpU<UP>>::conv(a.c1)}; }
+};
+
 template <class F>
 static inline XYZZ<typename HostField<F>::type> xyzz_to_host(const XYZZ<F>& p) {
   using H = HostField<F>;

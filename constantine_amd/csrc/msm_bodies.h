@@ -32,7 +32,7 @@ static constexpr uint32_t KEY_NONE = 0xffffffffu;
 // F  = coordinate field in the reference's representation (what the C API hands over and takes back)
 // FD = coordinate field the kernels compute in (carry-free limbs where that is faster, see fpu.h)
 struct Bls12381G1 { using F = Fp<BLS12_381_Fp>; using FD = FpU<BLS12_381_Fp_U>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 0; };
-struct Bls12381G2 { using F = Fp2<Fp<BLS12_381_Fp>>; using FD = F; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 1; };
+struct Bls12381G2 { using F = Fp2<Fp<BLS12_381_Fp>>; using FD = Fp2<FpU<BLS12_381_Fp_U>>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 1; };
 struct Bn254G1 { using F = Fp<BN254_Fp>; using FD = FpU<BN254_Fp_U>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; };
 struct Bn254G2 { using F = Fp2<Fp<BN254_Fp>>; using FD = F; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 3; };
 struct PallasEc { using F = Fp<Pallas_Fp>; using FD = FpU<Pallas_Fp_U>; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; };
@@ -91,18 +91,20 @@ CTT_HD void fr_from_mont_body(const uint32_t* in, uint32_t* out, uint32_t n, uin
 
 // Converted points are stored one per 128-byte line: after the sort every lane gathers whole points by index,
 // and a 112-byte (or 72-byte) record at its natural stride would straddle two cache lines most of the time.
-static constexpr uint32_t GATHER_STRIDE = 128;
+template <class FD>
+constexpr uint32_t gather_stride() {
+  return sizeof(Affine<FD>) <= 128 ? 128u : sizeof(Affine<FD>) <= 256 ? 256u : 512u;
+}
 
 // Input points: reference representation -> device field (one pass per MSM; (0,0) stays (0,0))
 template <class F, class FD>
 CTT_HD void convert_point_body(const Affine<F>* in, void* out, uint32_t n, uint32_t j) {
-  static_assert(sizeof(Affine<FD>) <= GATHER_STRIDE, "record must fit one line");
   if (j >= n) return;
   Affine<F> p = in[j];
   Affine<FD> q;
   q.x = FD::from_sat(p.x);
   q.y = FD::from_sat(p.y);
-  *(Affine<FD>*)((char*)out + (uint64_t)j * GATHER_STRIDE) = q;
+  *(Affine<FD>*)((char*)out + (uint64_t)j * gather_stride<FD>()) = q;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -167,10 +167,10 @@ struct MsmEngine {
     const void* d_points;
     uint32_t point_stride;
     if constexpr (kConvert) {
-      void* cp = need(cpoints, (size_t)n * GATHER_STRIDE);
+      void* cp = need(cpoints, (size_t)n * gather_stride<FD>());
       bk.template launch_convert<F, FD>(d_points_in, cp, n);
       d_points = cp;
-      point_stride = GATHER_STRIDE;
+      point_stride = gather_stride<FD>();
     } else {
       d_points = d_points_in;
       point_stride = (uint32_t)sizeof(Affine<F>);

@@ -73,6 +73,6 @@ def field_op_dev(curve, op, a, b=None):
     """Device-field probe: a, b in the reference representation; returns raw device limbs (uint32[NL])."""
     a = np.ascontiguousarray(a, dtype=np.uint8)
     b = a if b is None else np.ascontiguousarray(b, dtype=np.uint8)
-    out = np.zeros(32, dtype=np.uint32)
+    out = np.zeros(64, dtype=np.uint32)
     nl = lib().emu_field_op_dev(CURVE_ID[curve], op, _p(a), _p(b), _p(out))
     return out[:nl]
