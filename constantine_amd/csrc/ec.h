@@ -55,7 +55,7 @@ CTT_HD XYZZ<F> xyzz_mdbl(const F& x, const F& y) {
 }
 
 template <class F>
-CTT_HD_NOINLINE XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+CTT_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
   constexpr int M = F::MULB;
   if (p.is_inf()) return p;
   F U = F::dbl(p.y);                             // < 4M
@@ -71,9 +71,11 @@ CTT_HD_NOINLINE XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
 }
 
 // exceptional case of the mixed addition: same x. equal -> doubling of the affine point, opposite -> neutral.
-// Returns by value (the accumulator of the hot loop must never have its address taken: it would live in scratch).
+// Inlined on purpose: a device function call needs a stack frame in scratch memory, and any kernel whose scratch
+// demand (bytes/lane x resident lanes) crosses the runtime's per-queue limit is dispatched through the slow
+// allocate-per-launch path (measured: 2x on k_merge_tail, 2.5x on k_gen_points, box dependent).
 template <class F>
-CTT_HD_NOINLINE XYZZ<F> xyzz_madd_same_x(F qx, F qy, bool same_y) {
+CTT_HD XYZZ<F> xyzz_madd_same_x(const F& qx, const F& qy, bool same_y) {
   if (same_y) return xyzz_mdbl<F>(qx, qy);
   return XYZZ<F>::inf();
 }

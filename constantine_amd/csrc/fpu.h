@@ -84,7 +84,7 @@ struct FpU {
     return is_multiple_of_p(*this, B);
   }
   // rare path, kept out of line: compare against k*p limb by limb
-  static CTT_HD_NOINLINE bool is_multiple_of_p(FpU a, int B) {
+  static CTT_HD bool is_multiple_of_p(const FpU& a, int B) {
     bool hit = false;
     for (int k = 0; k < B; k++) {
       uint32_t d = 0;

@@ -229,8 +229,7 @@ CTT_HD void merge_step_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint3
   if ((rel % (2 * d)) != 0 || g + d > e) return;
   XYZZ<F> x = a.heads[slot];
   XYZZ<F> y = a.heads[slot + d];
-  xyzz_add<F>(x, y);
-  a.heads[slot] = x;
+  a.heads[slot] = xyzz_add_inl<F>(x, y);
 }
 
 // the first head of each chain now holds the bucket sum
