@@ -10,6 +10,7 @@ Only what the MSM hot path needs lives here:
 """
 from .curves import CURVES, CurveInfo  # noqa: F401
 from .msm import (  # noqa: F401
+    CachedBases,
     CttEngine,
     DeviceMsm,
     multiScalarMul_vartime,

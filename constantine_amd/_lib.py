@@ -23,7 +23,8 @@ def exported_symbols():
                 if par:
                     syms.append(f"ctt_{stem}_{coord}_multi_scalar_mul_{coef}_coefs_vartime_parallel")
     syms += ["ctt_hip_msm_abi_version", "ctt_hip_msm_ctx_create", "ctt_hip_msm_ctx_destroy", "ctt_hip_msm_set_option",
-             "ctt_hip_msm_device", "ctt_hip_msm_device_submit", "ctt_hip_msm_device_finish", "ctt_hip_msm_sync", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
+             "ctt_hip_msm_device", "ctt_hip_msm_device_submit", "ctt_hip_msm_device_finish", "ctt_hip_msm_sync", "ctt_hip_msm_bases_create", "ctt_hip_msm_bases_destroy",
+             "ctt_hip_msm_with_bases", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
              "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream"]
     return syms
 
@@ -55,6 +56,11 @@ def lib():
     L.ctt_hip_msm_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz]
     L.ctt_hip_msm_device_submit.argtypes = [vp, i32, i32, vp, vp, sz]
     L.ctt_hip_msm_device_finish.argtypes = [vp, i32, i32, vp]
+    L.ctt_hip_msm_bases_create.argtypes = [vp, i32, vp, sz, i32]
+    L.ctt_hip_msm_bases_create.restype = vp
+    L.ctt_hip_msm_bases_destroy.argtypes = [vp, vp]
+    L.ctt_hip_msm_bases_destroy.restype = None
+    L.ctt_hip_msm_with_bases.argtypes = [vp, vp, i32, i32, vp, vp, sz, i32]
     L.ctt_hip_msm_sync.argtypes = [vp]
     L.ctt_hip_msm_sync.restype = None
     L.ctt_hip_msm_last_timings.argtypes = [vp, vp, i32]

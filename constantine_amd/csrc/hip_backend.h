@@ -123,6 +123,9 @@ struct HipBackend {
   }
   void free(void* p) { HIP_CHECK(hipFree(p)); }
   void memset0(void* p, size_t b) { HIP_CHECK(hipMemsetAsync(p, 0, b, stream)); }
+  void d2d_async(void* dst, const void* src, size_t b) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToDevice, stream));
+  }
   void* alloc_host(size_t b) {
     void* p = nullptr;
     HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocDefault));
@@ -230,6 +233,10 @@ struct CurveOps {
   int (*submit)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
                 int* plan);
   void (*finish)(void* eng, int slot, void* r_host, int out_kind);
+  // cached bases: device records for `n` points (d_points in the C-API layout, device memory); submit against them
+  void* (*bases_prepare)(void* eng, const void* d_points, uint32_t n);
+  int (*submit_bases)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_prepared,
+                      uint32_t n, int* plan);
   void (*gen_points)(HipBackend* bk, uint64_t seed, uint64_t first, uint32_t n, void* d_out);
   void (*field_op)(HipBackend* bk, int op, const void* d_a, const void* d_b, void* d_r, uint32_t n);
   // host-only: r_aff = sum of n affine points (combining the per-GPU partial results of a sharded MSM,
@@ -271,6 +278,20 @@ struct CurveImpl {
     plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
     return sl;
   }
+  static void* bases_prepare(void* eng, const void* d_points, uint32_t n) {
+    return ((Engine*)eng)->prepare_bases((const Affine<F>*)d_points, n);
+  }
+  static int submit_bases(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_prepared,
+                          uint32_t n, int* plan) {
+    Engine& e = *(Engine*)eng;
+    uint32_t lanes = e.opt.lanes;
+    e.opt = *opt;
+    e.opt.lanes = lanes;
+    int sl = e.submit((const uint32_t*)d_coefs, coef_is_fr != 0, nullptr, n, d_prepared);
+    const MsmPlan& p = e.last_plan;
+    plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
+    return sl;
+  }
   static void finish(void* eng, int slot, void* r_host, int out_kind) {
     Engine& e = *(Engine*)eng;
     auto res = e.finish(slot);
@@ -303,7 +324,7 @@ struct CurveImpl {
     write_result<HF>(r_host, acc, out_kind);
   }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, run, submit, finish, gen_points, field_op, ec_sum_affine};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, run, submit, finish, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine};
     return &o;
   }
 };

@@ -140,7 +140,24 @@ struct MsmEngine {
 
   // d_coefs: canonical scalars [n][8] (coef_is_fr = false) or Montgomery Fr elements (true), device memory.
   // d_points: affine Montgomery points (reference representation), device memory.  Returns the slot.
-  int submit(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n) {
+  // Converted point records for base points that are reused across MSMs (the ZAL "base descriptor",
+  // constantine-halo2-zal/src/lib.rs:68-71): returns a device buffer owned by the caller (free with bk.free).
+  void* prepare_bases(const Affine<F>* d_points_in, uint32_t n) {
+    if (n == 0) return nullptr;
+    if constexpr (kConvert) {
+      void* cp = bk.alloc((size_t)n * gather_stride<FD>());
+      bk.template launch_convert<F, FD>(d_points_in, cp, n);
+      return cp;
+    } else {
+      void* cp = bk.alloc((size_t)n * sizeof(Affine<F>));
+      bk.d2d_async(cp, d_points_in, (size_t)n * sizeof(Affine<F>));
+      return cp;
+    }
+  }
+
+  // d_prepared (optional): records made by prepare_bases for the same points; skips the per-MSM conversion.
+  int submit(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n,
+             const void* d_prepared = nullptr) {
     const int sl = next_slot;
     Slot& S = slots[sl];
     if (S.busy) {
@@ -167,12 +184,16 @@ struct MsmEngine {
     const void* d_points;
     uint32_t point_stride;
     if constexpr (kConvert) {
-      void* cp = need(cpoints, (size_t)n * gather_stride<FD>());
-      bk.template launch_convert<F, FD>(d_points_in, cp, n);
-      d_points = cp;
+      if (d_prepared) {
+        d_points = d_prepared;
+      } else {
+        void* cp = need(cpoints, (size_t)n * gather_stride<FD>());
+        bk.template launch_convert<F, FD>(d_points_in, cp, n);
+        d_points = cp;
+      }
       point_stride = gather_stride<FD>();
     } else {
-      d_points = d_points_in;
+      d_points = d_prepared ? d_prepared : (const void*)d_points_in;
       point_stride = (uint32_t)sizeof(Affine<F>);
     }
     uint32_t* d_digits = (uint32_t*)need(digits, (size_t)W * n * 4);

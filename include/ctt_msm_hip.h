@@ -142,6 +142,16 @@ int ctt_hip_msm_device_finish(ctt_hip_msm_ctx* ctx, int ticket, int out_kind, vo
 /* Wait for everything enqueued on the context's stream(s) (successive submits alternate between two streams so
  * that the latency-bound tail of one MSM overlaps the next MSM's sort and accumulation). */
 void ctt_hip_msm_sync(ctt_hip_msm_ctx* ctx);
+/* Cached bases -- the Halo2-ZAL descriptor hooks (constantine-halo2-zal/src/lib.rs:60-95: get_base_descriptor,
+ * msm_with_cached_base): base points are uploaded and converted to the device representation once and stay resident
+ * in HBM; later MSMs move only the 32-byte coefficients. `points` / `coefs` are host pointers when the
+ * *_on_device flag is 0, device pointers when it is 1. ctt_hip_msm_with_bases uses the first `len` bases. */
+typedef struct ctt_hip_msm_bases ctt_hip_msm_bases;
+ctt_hip_msm_bases* ctt_hip_msm_bases_create(ctt_hip_msm_ctx* ctx, int curve, const void* points, size_t len,
+                                            int points_on_device);
+void ctt_hip_msm_bases_destroy(ctt_hip_msm_ctx* ctx, ctt_hip_msm_bases* bases);
+int ctt_hip_msm_with_bases(ctt_hip_msm_ctx* ctx, const ctt_hip_msm_bases* bases, int coef_kind, int out_kind, void* r,
+                           const void* coefs, size_t len, int coefs_on_device);
 /* HIP-event stage times (ms) of the last finished MSM: digits, sort, accumulate, merge, reduce, total. */
 int ctt_hip_msm_last_timings(ctt_hip_msm_ctx* ctx, float* ms, int cap);
 /* plan of the last call: c, W, K, G, S, resident lanes */

@@ -16,6 +16,7 @@ struct EmuBackend {
   void* alloc(size_t b) { return malloc(b); }
   void free(void* p) { ::free(p); }
   void memset0(void* p, size_t b) { memset(p, 0, b); }
+  void d2d_async(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void* alloc_host(size_t b) { return malloc(b); }
   void free_host(void* p) { ::free(p); }
   void d2h_async(int, void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
@@ -131,8 +132,16 @@ struct EmuCurve {
     eng.opt.S = S;
     eng.opt.lanes = 4096;
     // exercise both in-flight slots: submit twice, finish in order
-    int s0 = eng.submit((const uint32_t*)coefs, coef_is_fr != 0, (const Affine<F>*)points, (uint32_t)n);
+    // K < 0 in the test harness means: go through the cached-base path (prepare_bases + submit against it)
+    void* prepared = nullptr;
+    if (K < 0) {
+      eng.opt.K = -K;
+      prepared = eng.prepare_bases((const Affine<F>*)points, (uint32_t)n);
+    }
+    int s0 = eng.submit((const uint32_t*)coefs, coef_is_fr != 0, prepared ? nullptr : (const Affine<F>*)points, (uint32_t)n,
+                        prepared);
     auto res = eng.finish(s0);
+    if (prepared) bk.free(prepared);
     write_result<typename MsmEngine<C, EmuBackend>::HF>(r, res, out_kind);
     if (plan_out && n) {
       plan_out[0] = eng.last_plan.c; plan_out[1] = eng.last_plan.W; plan_out[2] = (int)eng.last_plan.K;

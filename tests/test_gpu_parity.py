@@ -152,7 +152,10 @@ def test_halo2_zal_engine_entry():
         can, mont = curve.scalars_to_array(ks), curve.fr_scalars_to_array(ks)
         expect = _aff(curve, cref.msm(name, can, pts, nthreads=NT)[0])
         assert curve.prj_from_bytes(bytes(eng.msm(mont, pts))) == expect
-        assert curve.prj_from_bytes(bytes(eng.msm_with_cached_base(mont, eng.get_base_descriptor(pts)))) == expect
+        desc = eng.get_base_descriptor(pts)           # uploads + converts the bases once (lib.rs:68-71)
+        assert curve.prj_from_bytes(bytes(eng.msm_with_cached_base(mont, desc))) == expect
+        assert curve.prj_from_bytes(bytes(eng.msm_with_cached_base(mont, desc))) == expect
+        desc.close()
 
 
 @pytest.mark.parametrize("group,cname", [("g1", "bls12_381_g1"), ("g2", "bls12_381_g2")])
@@ -330,3 +333,20 @@ def test_two_msms_in_flight(dev, torch_cuda, lanes):
         assert bytes(dev.finish(pending, coord="aff")) == data[i][3], sizes[i]
         pending = nxt
     dev.set_option("lanes", 1)
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "pallas", "bls12_381_g2", "bn254_snarks_g2"])
+def test_cached_bases_prefix_and_reuse(name):
+    """ctt_hip_msm_bases_*: bases converted once, reused with different coefficient vectors and prefixes."""
+    from constantine_amd import CachedBases
+    curve = po.CURVES[name]
+    n = 3000 if curve.F.degree == 1 else 300
+    pts = cref.gen_points(name, 901, n)
+    bases = CachedBases(name, pts)
+    try:
+        for seed, m in ((1, n), (2, n), (3, n // 3), (4, 1)):
+            sc = cref.synth_scalars(seed, m, curve.scalar_bits)
+            expect = _aff(curve, cref.msm(name, sc, pts[:m], nthreads=NT)[0])
+            assert _decode(curve, "jac", bases.msm(sc, coord="jac")) == expect
+    finally:
+        bases.close()
