@@ -54,3 +54,58 @@ def eip2537(group):
             E = ((es[0], es[1]), (es[2], es[3]))
         out.append((name, scalars, points, E))
     return out
+
+
+# ---- EIP-4844 blob -> KZG commitment (N = 4096 G1 MSM) ------------------------------------------------------
+_BLS_P = po.BLS12_381_G1.F.p
+
+
+def g1_decompress(b48: bytes):
+    """ZCash BLS12-381 G1 encoding: bit 7 compression flag, bit 6 infinity, bit 5 = y is the larger root."""
+    assert len(b48) == 48 and b48[0] & 0x80
+    if b48[0] & 0x40:
+        return None
+    x = int.from_bytes(b48, "big") & ((1 << 381) - 1)
+    y2 = (pow(x, 3, _BLS_P) + 4) % _BLS_P
+    y = pow(y2, (_BLS_P + 1) // 4, _BLS_P)
+    assert y * y % _BLS_P == y2, "not on the curve"
+    if bool(b48[0] & 0x20) != (y > (_BLS_P - 1) // 2):
+        y = _BLS_P - y
+    return (x, y)
+
+
+def g1_compress(P) -> bytes:
+    if P is None:
+        return bytes([0xC0]) + bytes(47)
+    x, y = P
+    b = bytearray(x.to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if y > (_BLS_P - 1) // 2 else 0)
+    return bytes(b)
+
+
+def _bit_reverse_permutation(seq):
+    n = len(seq)
+    bits = n.bit_length() - 1
+    return [seq[int(format(i, f"0{bits}b")[::-1], 2)] for i in range(n)]
+
+
+def kzg4844_setup_points():
+    """The 4096 Lagrange-form G1 points in the order commitments use them: bit-reversal permutation of the file
+    order (EIP-4844 `bit_reversal_permutation(KZG_SETUP_G1_LAGRANGE)`; the reference applies it when it loads the
+    setup, constantine/commitments_setups/ethereum_kzg_srs.nim)."""
+    raw = open(os.path.join(HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read()
+    pts = [g1_decompress(raw[48 * i:48 * i + 48]) for i in range(4096)]
+    return _bit_reverse_permutation(pts)
+
+
+def kzg4844_cases():
+    """-> [(name, [4096 scalars], commitment_bytes)]; blob = 4096 big-endian 32-byte field elements."""
+    import base64
+    import zlib
+    out = []
+    for name, z, com in json.load(open(os.path.join(HERE, "kzg4844_blob_to_commitment.json"))):
+        blob = zlib.decompress(base64.b64decode(z))
+        assert len(blob) == 4096 * 32
+        scalars = [int.from_bytes(blob[32 * i:32 * i + 32], "big") for i in range(4096)]
+        out.append((name, scalars, bytes.fromhex(com)))
+    return out

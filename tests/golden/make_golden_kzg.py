@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""
+Re-encode the reference's EIP-4844 `blob_to_kzg_commitment` vectors (a 4096-point BLS12-381 G1 MSM through
+kzg_commit, constantine/commitments/kzg.nim:186) into small fixtures.  Run where /root/reference exists:
+
+    python tests/golden/make_golden_kzg.py
+
+Sources (reference-relative):
+  constantine/commitments_setups/trusted_setup_ethereum_kzg4844_reference.dat
+      text form of the Ethereum KZG ceremony output: "4096\\n65\\n" then one hex line per point; the first 4096
+      lines are the G1 points of the SRS in Lagrange form, 48-byte compressed (ZCash encoding)
+      -> kzg4844_srs_g1_lagrange.bin   (4096 x 48 bytes, file order)
+  tests/protocol_ethereum_eip4844_deneb_kzg/blob_to_kzg_commitment/kzg-mainnet/*valid_blob*/data.yaml
+      -> kzg4844_blob_to_commitment.json : [[case, zlib+base64(blob), commitment_hex], ...]
+      (the four structured blobs and one of the random ones; the other two random blobs add nothing but 256 KB)
+"""
+import base64
+import glob
+import json
+import os
+import re
+import zlib
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    lines = open(f"{REF}/constantine/commitments_setups/trusted_setup_ethereum_kzg4844_reference.dat").read().split()
+    n1, n2 = int(lines[0]), int(lines[1])
+    assert (n1, n2) == (4096, 65)
+    g1 = b"".join(bytes.fromhex(h) for h in lines[2:2 + n1])
+    assert len(g1) == 4096 * 48
+    open(os.path.join(HERE, "kzg4844_srs_g1_lagrange.bin"), "wb").write(g1)
+
+    cases = []
+    base = f"{REF}/tests/protocol_ethereum_eip4844_deneb_kzg/blob_to_kzg_commitment/kzg-mainnet"
+    random_kept = 0
+    for d in sorted(glob.glob(f"{base}/*valid_blob*")):
+        if "invalid" in d:
+            continue
+        t = open(f"{d}/data.yaml").read()
+        blob = bytes.fromhex(re.search(r"blob: '0x([0-9a-f]+)'", t).group(1))
+        out = re.search(r"output: '0x([0-9a-f]+)'", t).group(1)
+        z = zlib.compress(blob, 9)
+        if len(z) > 4096:
+            if random_kept:
+                continue
+            random_kept += 1
+        cases.append([os.path.basename(d), base64.b64encode(z).decode(), out])
+    json.dump(cases, open(os.path.join(HERE, "kzg4844_blob_to_commitment.json"), "w"), separators=(",", ":"))
+    print(len(cases), "cases;", os.path.getsize(os.path.join(HERE, "kzg4844_blob_to_commitment.json")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""EIP-4844 blob_to_kzg_commitment known answers: a 4096-point BLS12-381 G1 MSM through the path
+kzg_commit -> multiScalarMul_vartime (constantine/commitments/kzg.nim:186; vectors from
+tests/protocol_ethereum_eip4844_deneb_kzg/blob_to_kzg_commitment/kzg-mainnet)."""
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import pyoracle as po
+from tests import _golden
+
+CURVE = po.BLS12_381_G1
+NAME = "bls12_381_g1"
+
+
+@pytest.fixture(scope="module")
+def setup():
+    pts = _golden.kzg4844_setup_points()
+    assert all(CURVE.is_on_curve(P) for P in pts[:16])
+    return pts, CURVE.points_to_array(pts)
+
+
+def test_oracle_reproduces_commitments(setup):
+    pts, pts_arr = setup
+    cases = _golden.kzg4844_cases()
+    assert len(cases) >= 5
+    for name, scalars, commitment in cases:
+        assert all(k < CURVE.order for k in scalars)
+        sc = CURVE.scalars_to_array(scalars)
+        out, _ = cref.msm(NAME, sc, pts_arr, nthreads=4)
+        assert _golden.g1_compress(CURVE.aff_from_bytes(bytes(out))) == commitment, name
+    # and once through the pure-Python bucket method, on the smallest non-trivial case
+    name, scalars, commitment = min(cases, key=lambda c: sum(1 for k in c[1] if k))
+    assert _golden.g1_compress(CURVE.msm_pippenger(scalars, pts, c=8)) == commitment
+
+
+def test_emulated_kernels_reproduce_commitments(setup):
+    from tests.emu import emu
+    _, pts_arr = setup
+    for name, scalars, commitment in _golden.kzg4844_cases()[:3]:
+        sc = CURVE.scalars_to_array(scalars)
+        out, _ = emu.msm(NAME, sc, pts_arr)
+        assert _golden.g1_compress(CURVE.aff_from_bytes(bytes(out))) == commitment, name
+        mont = CURVE.fr_scalars_to_array(scalars)     # kzg_commit hands Fr elements (fr_coefs entry)
+        out, _ = emu.msm(NAME, mont, pts_arr, coef_is_fr=True)
+        assert _golden.g1_compress(CURVE.aff_from_bytes(bytes(out))) == commitment, name
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_commitments(setup):
+    from constantine_amd import CachedBases, multiScalarMul_vartime_parallel
+    _, pts_arr = setup
+    bases = CachedBases(NAME, pts_arr)      # the SRS is the textbook cached-base case
+    try:
+        for name, scalars, commitment in _golden.kzg4844_cases():
+            mont = CURVE.fr_scalars_to_array(scalars)
+            r = multiScalarMul_vartime_parallel(None, NAME, mont, pts_arr, coord="jac", fr_coefs=True)
+            assert _golden.g1_compress(CURVE.jac_from_bytes(bytes(r))) == commitment, name
+            r = bases.msm(CURVE.scalars_to_array(scalars), coord="prj")
+            assert _golden.g1_compress(CURVE.prj_from_bytes(bytes(r))) == commitment, name
+    finally:
+        bases.close()
