@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="pairs timed on the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); gloo is for "
+                    "exercising the multi-rank path on a single-GPU box together with --all-ranks-on-device")
+    ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="testing: put every rank on this GPU")
     args = ap.parse_args()
 
     import torch
@@ -68,10 +71,15 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if args.all_ranks_on_device >= 0:
+        local_rank = args.all_ranks_on_device
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from constantine_amd import CURVES, DeviceMsm
     from constantine_amd import parallel
@@ -126,7 +134,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -21,14 +21,11 @@ struct MsmPlan {
   uint32_t slice;  // scalars per slice
   uint32_t K;      // sorted entries per accumulate lane
   uint32_t G;      // accumulate lanes per window
-  uint32_t rs;     // bucket-reduce chunk (power of two)
-  uint32_t rlog;
 };
 
 struct MsmOptions {
   int c = 0;          // window bits (0 = choose)
   int K = 0;          // entries per lane (0 = choose from resident lanes)
-  int rs_log = 3;     // reduce chunk = 2^rs_log
   int S = 0;          // sort slices (0 = choose)
   uint32_t lanes = 196608;  // resident lanes of the accumulate kernel (set by the backend)
 };
@@ -69,8 +66,6 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   if (K < 4) K = 4;
   p.K = K;
   p.G = (n + K - 1) / K;
-  p.rlog = (uint32_t)o.rs_log;
-  p.rs = 1u << p.rlog;
   return p;
 }
 

@@ -23,7 +23,7 @@ def lib():
     if _lib is None:
         L = ctypes.CDLL(build())
         vp, sz, i32, u64, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32
-        L.emu_msm.argtypes = [i32, i32, i32, vp, vp, vp, sz, i32, i32, i32, i32, vp]
+        L.emu_msm.argtypes = [i32, i32, i32, vp, vp, vp, sz, i32, i32, i32, vp]
         L.emu_gen_points.argtypes = [i32, u64, u64, u32, vp]
         L.emu_field_op.argtypes = [i32, i32, vp, vp, vp]
         L.emu_field_op_dev.argtypes = [i32, i32, vp, vp, vp]
@@ -36,14 +36,14 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def msm(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, K=0, rs_log=0, S=0):
+def msm(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, K=0, S=0):
     coefs = np.ascontiguousarray(coefs, dtype=np.uint8)
     points = np.ascontiguousarray(points, dtype=np.uint8)
     n = coefs.shape[0]
     nco = 2 if out_kind == 0 else 3
     out = np.zeros(AFF_BYTES[curve] // 2 * nco, dtype=np.uint8)
     plan = np.zeros(8, dtype=np.int32)
-    rc = lib().emu_msm(CURVE_ID[curve], int(coef_is_fr), out_kind, _p(out), _p(coefs), _p(points), n, c, K, rs_log, S, _p(plan))
+    rc = lib().emu_msm(CURVE_ID[curve], int(coef_is_fr), out_kind, _p(out), _p(coefs), _p(points), n, c, K, S, _p(plan))
     assert rc == 0
     return out, plan
 

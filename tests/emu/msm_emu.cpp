@@ -108,7 +108,7 @@ struct EmuBackend {
 // ---------------------------------------------------------------------------------------------
 struct EmuOps {
   int (*msm)(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c, int K,
-             int rs_log, int S, int* plan_out);
+             int S, int* plan_out);
   void (*gen)(uint64_t seed, uint64_t first, uint32_t n, void* out);
   void (*fop)(int op, const void* a, const void* b, void* r);
   int (*fop_dev)(int op, const void* a, const void* b, void* r);
@@ -123,12 +123,11 @@ struct EmuCurve {
   using F = typename C::F;
   using FD = typename C::FD;
   static int msm(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c, int K,
-                 int rs_log, int S, int* plan_out) {
+                 int S, int* plan_out) {
     EmuBackend bk;
     MsmEngine<C, EmuBackend> eng(bk);
     eng.opt.c = c;
     eng.opt.K = K;
-    if (rs_log > 0) eng.opt.rs_log = rs_log;
     eng.opt.S = S;
     eng.opt.lanes = 4096;
     // exercise both in-flight slots: submit twice, finish in order
@@ -234,9 +233,9 @@ static const EmuOps* ops_of(int curve) {
 }
 
 int emu_msm(int curve, int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c,
-            int K, int rs_log, int S, int* plan_out) {
+            int K, int S, int* plan_out) {
   const EmuOps* o = ops_of(curve);
-  return o ? o->msm(coef_is_fr, out_kind, r, coefs, points, n, c, K, rs_log, S, plan_out) : -1;
+  return o ? o->msm(coef_is_fr, out_kind, r, coefs, points, n, c, K, S, plan_out) : -1;
 }
 int emu_gen_points(int curve, uint64_t seed, uint64_t first, uint32_t n, void* out) {
   const EmuOps* o = ops_of(curve);

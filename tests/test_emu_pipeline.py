@@ -112,7 +112,7 @@ def test_msm_vs_oracle(name, n):
     sc = cref.synth_scalars(4, n, curve.scalar_bits)
     expect, _ = cref.msm(name, sc, pts)
     # K < 0: the emulator harness routes the call through prepare_bases + submit(prepared) (cached-base path)
-    for kw in (dict(), dict(c=3, K=4), dict(c=5, K=8, rs_log=1), dict(c=7, K=4, rs_log=2, S=1), dict(c=6, K=-8)):
+    for kw in (dict(), dict(c=3, K=4), dict(c=5, K=8), dict(c=7, K=4, S=1), dict(c=6, K=-8)):
         out, plan = emu.msm(name, sc, pts, **kw)
         assert bytes(out) == bytes(expect), (kw, plan)
 

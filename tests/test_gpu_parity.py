@@ -234,7 +234,7 @@ def test_all_equal_points_bug366_style():
 
 
 def test_window_sizes_and_lane_spans(dev, torch_cuda):
-    """Same answer for every plan: window bits (incl. divisors of the scalar width), entries per lane, reduce chunk."""
+    """Same answer for every plan: window bits (incl. divisors of the scalar width), entries per lane, sort slices."""
     torch = torch_cuda
     name = "bls12_381_g1"
     curve = po.CURVES[name]
@@ -246,15 +246,15 @@ def test_window_sizes_and_lane_spans(dev, torch_cuda):
     expect = bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
     dp, ds = _to_dev(torch, pts), _to_dev(torch, sc)
     try:
-        for c, K, rs in ((3, 4, 1), (5, 8, 2), (8, 16, 3), (13, 0, 3), (15, 12, 4), (16, 0, 3), (0, 0, 0)):
+        for c, K, S in ((3, 4, 0), (5, 8, 1), (8, 16, 3), (13, 0, 0), (15, 12, 2), (16, 0, 0), (0, 0, 0)):
             dev.set_option("c", c)
             dev.set_option("K", K)
-            dev.set_option("rs_log", rs)
-            assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (c, K, rs, dev.last_plan())
+            dev.set_option("S", S)
+            assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (c, K, S, dev.last_plan())
     finally:
         dev.set_option("c", 0)
         dev.set_option("K", 0)
-        dev.set_option("rs_log", 0)
+        dev.set_option("S", 0)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -95,21 +95,6 @@ __global__ void k_field_chain(uint32_t* out, uint32_t seed, int iters) {
   out[tid] = s;
 }
 
-// XYZZ mixed-add chain (the hot loop body of k_accum, data in registers)
-template <class F>
-__global__ void k_madd_chain(uint32_t* out, const Affine<F>* pts, int npts, int iters) {
-  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  XYZZ<F> acc = XYZZ<F>::inf();
-  Affine<F> p = pts[tid % npts];
-  for (int i = 0; i < iters; i++) {
-    xyzz_madd<F>(acc, p, (i & 1) != 0);
-    p.x.l[0] ^= acc.x.l[0] & 1;  // keep the compiler from hoisting; stays a valid-enough operand for timing
-  }
-  uint32_t s = 0;
-  for (int i = 0; i < F::N; i++) s ^= acc.x.l[i] ^ acc.zz.l[i];
-  out[tid] = s;
-}
-
 template <class K, class... A>
 static double time_kernel(K kern, dim3 grid, dim3 block, int reps, A... args) {
   hipEvent_t e0, e1;
@@ -185,19 +170,5 @@ int main(int argc, char** argv) {
     RUNF("bn254_fp_sqr", F254, 1, wps)
   }
 
-  // mixed-add chain
-  {
-    Affine<F381> g = generator<Bls12381G1>();  // host-side call of the HD function
-    Affine<F381>* dp;
-    CK(hipMalloc(&dp, sizeof(g)));
-    CK(hipMemcpy(dp, &g, sizeof(g), hipMemcpyHostToDevice));
-    for (int wps : {1, 2, 3}) {
-      int nb = cus * wps * 4;  // 64-thread blocks
-      const int it = 128;
-      double t = time_kernel(k_madd_chain<F381>, dim3(nb), dim3(64), 3, out, dp, 1, it);
-      double ops = (double)nb * 64 * it;
-      printf("{\"ec_op\": \"bls12_381_g1_xyzz_madd\", \"waves_per_simd\": %d, \"Gadds_per_s\": %.3f}\n", wps, ops / t / 1e9);
-    }
-  }
   return 0;
 }
