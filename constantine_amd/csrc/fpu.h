@@ -81,6 +81,9 @@ struct FpU {
 #pragma unroll
     for (int k = 0; k < B; k++) maybe |= (l[0] == kp(k).l[0]);
     if (!maybe) return false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");  // keep the full comparison behind a real branch (hipcc otherwise speculates it)
+#endif
     return is_multiple_of_p(*this, B);
   }
   // rare path, kept out of line: compare against k*p limb by limb

@@ -1,0 +1,41 @@
+/* tests/c_api/t_msm_c_abi.c -- calls the Constantine-compatible MSM symbols from plain C through
+ * include/ctt_msm_hip.h, the way a C user of constantine.h would (the reference's own C tests,
+ * tests/c_api/t_threadpool.c and examples-c/, never call MSM).
+ *
+ * usage: t_msm_c_abi <in.bin> <out.bin>
+ *   in.bin : u64 n | n * big255 (32 B) | n * bls12_381_g1_aff (96 B)
+ *   out.bin: bls12_381_g1_jac (parallel symbol, big coefs) | bls12_381_g1_prj (serial symbol, big coefs)
+ * Built and driven by tests/test_gpu_parity.py::test_c_program_through_the_header. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "ctt_msm_hip.h"
+
+int main(int argc, char** argv) {
+  if (argc != 3) return 2;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 3;
+  uint64_t n = 0;
+  if (fread(&n, sizeof n, 1, f) != 1) return 4;
+  big255* coefs = (big255*)malloc(n * sizeof(big255));
+  bls12_381_g1_aff* points = (bls12_381_g1_aff*)malloc(n * sizeof(bls12_381_g1_aff));
+  if (fread(coefs, sizeof(big255), n, f) != n) return 5;
+  if (fread(points, sizeof(bls12_381_g1_aff), n, f) != n) return 6;
+  fclose(f);
+
+  bls12_381_g1_jac rj;
+  bls12_381_g1_prj rp;
+  const ctt_threadpool* tp = NULL; /* accepted and ignored by the GPU engine */
+  ctt_bls12_381_g1_jac_multi_scalar_mul_big_coefs_vartime_parallel(tp, &rj, coefs, points, (size_t)n);
+  ctt_bls12_381_g1_prj_multi_scalar_mul_big_coefs_vartime(&rp, coefs, points, (size_t)n);
+
+  f = fopen(argv[2], "wb");
+  if (!f) return 7;
+  fwrite(&rj, sizeof rj, 1, f);
+  fwrite(&rp, sizeof rp, 1, f);
+  fclose(f);
+  free(coefs);
+  free(points);
+  return 0;
+}

@@ -350,3 +350,30 @@ def test_cached_bases_prefix_and_reuse(name):
             assert _decode(curve, "jac", bases.msm(sc, coord="jac")) == expect
     finally:
         bases.close()
+
+
+def test_c_program_through_the_header(tmp_path):
+    """A plain C program including include/ctt_msm_hip.h, linked against libctt_msm_hip.so, gets the oracle's answer."""
+    import subprocess
+    from constantine_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "t_msm_c_abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_api", "t_msm_c_abi.c"), "-L", libdir, "-lctt_msm_hip",
+                           f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    name = "bls12_381_g1"
+    curve = po.CURVES[name]
+    n = 1500
+    pts = cref.gen_points(name, 77, n)
+    sc = cref.synth_scalars(78, n, 255)
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.uint64(n).tobytes())
+        f.write(sc.tobytes())
+        f.write(pts.tobytes())
+    subprocess.check_call([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    out = open(tmp_path / "out.bin", "rb").read()
+    assert len(out) == 2 * 144
+    expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
+    assert curve.jac_from_bytes(out[:144]) == expect
+    assert curve.prj_from_bytes(out[144:]) == expect
