@@ -293,6 +293,29 @@ def test_bls12_381_g1_2pow20(dev, torch_cuda):
     _full_size("bls12_381_g1", 20, dev, torch_cuda, check_oracle=True)
 
 
+def test_bls12_381_g1_2pow24_properties(dev, torch_cuda):
+    """BASELINE config 4 size (2^24 pairs) on one GPU: size-independent properties + sharded-sum identity over 8 slices
+    (what the 8-GPU run computes: MSM = sum of the per-rank MSMs over balanced slices)."""
+    torch = torch_cuda
+    from constantine_amd.msm import ec_sum_affine
+    from constantine_amd.parallel import shard_bounds
+    name = "bls12_381_g1"
+    n = 1 << 24
+    dp = torch.empty((n, 96), dtype=torch.uint8, device="cuda")
+    dev.gen_points(name, 2424, n, dp)
+    ds = _to_dev(torch, cref.synth_scalars(2425, n, 255))
+    full = dev.msm(name, ds, dp, n, coord="aff")
+    parts = []
+    for r in range(8):
+        s0, ln = shard_bounds(n, 8, r)
+        parts.append(dev.msm(name, ds[s0:s0 + ln], dp[s0:s0 + ln], ln, coord="aff"))
+    assert bytes(ec_sum_affine(name, np.stack(parts))) == bytes(full)
+    # oracle on a prefix
+    m = 1 << 18
+    expect, _ = cref.msm(name, ds[:m].cpu().numpy(), dp[:m].cpu().numpy(), nthreads=NT)
+    assert bytes(dev.msm(name, ds[:m], dp[:m], m, coord="aff")) == bytes(expect)
+
+
 def test_bn254_g1_2pow22_properties(dev, torch_cuda):
     """BASELINE config 3 size (2^22); oracle comparison on the first 2^18 pairs."""
     torch = torch_cuda
