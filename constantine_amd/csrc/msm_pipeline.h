@@ -31,14 +31,41 @@ struct MsmOptions {
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
-// (ec_multi_scalar_mul_scheduler.nim:172-223) models a CPU; any c yields the same group element,
-// so the device uses its own cost model: W * (N mixed adds (10 mul) + 2^(c-1) buckets * ~2.3 full adds (14 mul)).
-static inline int choose_window_bits(uint32_t n, int bits) {
+// (ec_multi_scalar_mul_scheduler.nim:172-223) models a CPU; any c yields the same group element, so the device
+// uses its own cost model with constants measured on MI355X for BLS12-381 (profiles/): they only rank the
+// candidates, so the same model serves the other curves.
+//   accumulate  W*N mixed adds at 0.155 ns each (2.6 ms / 2^24 at full occupancy)
+//   reduce      c-1 passes, each at least one EC-add latency (17 us), plus 2*2^(c-1)*W adds of work
+//   merge       55 us + one 21 us tree step per doubling of the longest head chain.  The top window only has
+//               bits - (W-1)*c significant bits: when that is small its few buckets each receive N/2^(top-1)
+//               entries and the chain is long -- the model steers away from such c (e.g. c = 14 at N = 2^18)
+//   sort        0.02 ns per (window, pair) + 60 us
+static inline uint32_t plan_entries_per_lane(uint32_t n, int W, uint32_t lanes) {
+  uint64_t total = (uint64_t)W * n;
+  uint32_t K = (uint32_t)((total + lanes - 1) / lanes);
+  K = (K + 3u) & ~3u;
+  return K < 4 ? 4 : K;
+}
+
+static inline int choose_window_bits(uint32_t n, int bits, uint32_t lanes) {
   double best = 1e300;
-  int bc = 2;
-  for (int c = 2; c <= 16; c++) {
-    double W = bits / c + 1;
-    double cost = W * (10.0 * n + 32.0 * (double)(1u << (c - 1)) + 2000.0);
+  int bc = 8;
+  for (int c = 6; c <= 16; c++) {
+    const int W = bits / c + 1;
+    const double B = (double)(1u << (c - 1));
+    const double K = (double)plan_entries_per_lane(n, W, lanes);
+    const double acc = (double)W * n * 0.155e-3;
+    const double red = (c - 1) * 17.0 + 2.0 * B * W * 0.25e-3;
+    const int top = bits - (W - 1) * c;  // 0: the extra window only carries the Booth carry bit
+    const double top_buckets = top > 1 ? (double)(1u << (top - 1)) : 1.0;
+    double maxcnt = (double)n / top_buckets;
+    if (maxcnt < 2.0 * n / B) maxcnt = 2.0 * n / B;
+    double chain = maxcnt / K;
+    int steps = 0;
+    while (chain > 1.0) { chain *= 0.5; steps++; }
+    const double mer = 55.0 + 21.0 * steps;
+    const double srt = (double)W * n * 0.02e-3 + 60.0;
+    const double cost = acc + red + mer + srt;
     if (cost < best) { best = cost; bc = c; }
   }
   return bc;
@@ -47,7 +74,7 @@ static inline int choose_window_bits(uint32_t n, int bits) {
 static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   MsmPlan p;
   p.n = n;
-  p.c = o.c > 0 ? o.c : choose_window_bits(n, bits);
+  p.c = o.c > 0 ? o.c : choose_window_bits(n, bits, o.lanes);
   if (p.c < 2) p.c = 2;
   if (p.c > 16) p.c = 16;
   p.W = bits / p.c + 1;  // ec_multi_scalar_mul_parallel.nim:157-158: one more window when c | bits
@@ -60,8 +87,7 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   p.S = S;
   p.slice = (n + S - 1) / S;
   // entries per lane: fill the resident lanes once
-  uint64_t total = (uint64_t)p.W * n;
-  uint32_t K = o.K > 0 ? (uint32_t)o.K : (uint32_t)((total + o.lanes - 1) / o.lanes);
+  uint32_t K = o.K > 0 ? (uint32_t)o.K : plan_entries_per_lane(n, p.W, o.lanes);
   K = (K + 3u) & ~3u;
   if (K < 4) K = 4;
   p.K = K;
