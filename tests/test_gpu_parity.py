@@ -83,6 +83,50 @@ def test_field_ops_on_device(name, dev, torch_cuda):
             assert F.from_mont_bytes(bytes(out[i])) == fn(A[i], B[i]), (name, op, i)
 
 
+DEV_FIELD = {"bls12_381_g1": (28, 14, 1), "bls12_381_g2": (28, 14, 2), "bn254_snarks_g1": (29, 9, 1),
+             "pallas": (29, 9, 1), "vesta": (29, 9, 1)}   # (limb bits, limbs per base element, degree), fpu.h
+
+
+@pytest.mark.parametrize("name", list(DEV_FIELD))
+def test_carry_free_field_on_device(name, dev, torch_cuda):
+    """The field the kernels compute in (fpu.h): x*R' mod p in LB-bit limbs, normalised, bounded by a few p."""
+    torch = torch_cuda
+    lb, nl, deg = DEV_FIELD[name]
+    curve = po.CURVES[name]
+    F = curve.F
+    base = F if deg == 1 else F.base
+    p = base.p
+    Rp_inv = pow(1 << (lb * nl), -1, p)
+    rng = random.Random(13)
+    n = 1024
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, base.R % p, (1 << (lb * nl)) % p]
+
+    def rnd():
+        c = [rng.choice(edge) if rng.random() < 0.15 else rng.randrange(p) for _ in range(deg)]
+        return c[0] if deg == 1 else tuple(c)
+
+    A = [rnd() for _ in range(n)]
+    B = [rnd() for _ in range(n)]
+    a = np.frombuffer(b"".join(F.to_mont_bytes(x) for x in A), dtype=np.uint8).reshape(n, -1).copy()
+    b = np.frombuffer(b"".join(F.to_mont_bytes(x) for x in B), dtype=np.uint8).reshape(n, -1).copy()
+    da, db = _to_dev(torch, a), _to_dev(torch, b)
+    dr = torch.zeros((n, nl * deg), dtype=torch.int32, device="cuda")
+    ops = {0: (F.mul, 2), 1: (lambda x, y: F.sqr(x), 2), 2: (F.add, 4), 3: (F.sub, 4), 4: (lambda x, y: x, 2)}
+    for op, (fn, bound) in ops.items():
+        dev.field_op(name, 16 + op, da, db, dr, n)
+        out = dr.cpu().numpy().astype(np.uint32)
+        for i in range(n):
+            comps = []
+            for k in range(deg):
+                limbs = [int(x) for x in out[i, k * nl:(k + 1) * nl]]
+                assert all(x < (1 << lb) for x in limbs[:-1])
+                v = sum(x << (lb * j) for j, x in enumerate(limbs))
+                assert v < bound * p
+                comps.append(v * Rp_inv % p)
+            got = comps[0] if deg == 1 else tuple(comps)
+            assert got == fn(A[i], B[i]), (name, op, i)
+
+
 @pytest.mark.parametrize("name", ALL)
 def test_gen_points_matches_oracle(name, dev, torch_cuda):
     torch = torch_cuda
