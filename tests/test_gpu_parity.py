@@ -444,3 +444,32 @@ def test_c_program_through_the_header(tmp_path):
     expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
     assert curve.jac_from_bytes(out[:144]) == expect
     assert curve.prj_from_bytes(out[144:]) == expect
+
+
+def test_concurrent_callers_are_serialised():
+    """Several host threads calling the Constantine symbols at once (the reference allows MSM calls from inside
+    pool tasks, ec_multi_scalar_mul_parallel.nim:596; KZG batch verification issues three at a time): the engine
+    serialises them on its context and every caller gets its own answer."""
+    import threading
+    from constantine_amd import multiScalarMul_vartime_parallel
+    jobs = []
+    for i, (name, n) in enumerate([("bls12_381_g1", 3000), ("bn254_snarks_g1", 5000), ("pallas", 700),
+                                   ("bls12_381_g1", 64), ("vesta", 2048), ("bn254_snarks_g1", 1)]):
+        curve = po.CURVES[name]
+        pts = cref.gen_points(name, 1300 + i, n)
+        sc = cref.synth_scalars(1400 + i, n, curve.scalar_bits)
+        jobs.append((name, curve, sc, pts, _aff(curve, cref.msm(name, sc, pts, nthreads=4)[0])))
+    results = [None] * len(jobs)
+
+    def work(k):
+        name, curve, sc, pts, _ = jobs[k]
+        for _ in range(3):
+            results[k] = curve.jac_from_bytes(bytes(multiScalarMul_vartime_parallel(None, name, sc, pts, coord="jac")))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k, job in enumerate(jobs):
+        assert results[k] == job[4], job[0]
