@@ -59,3 +59,52 @@ def test_gpu_reproduces_commitments(setup):
             assert _golden.g1_compress(CURVE.prj_from_bytes(bytes(r))) == commitment, name
     finally:
         bases.close()
+
+
+# ---- the protocol-level caller (constantine_amd/kzg.py) -----------------------------------------------------
+def test_kzg_codec_and_validation_host_logic():
+    """Host logic of the KZG layer needs no GPU: point codec round trip, blob parsing, rejection of bad blobs."""
+    import os
+    from constantine_amd import kzg
+    raw = open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read()
+    for i in (0, 1, 77, 4095):
+        c = raw[48 * i:48 * i + 48]
+        P = kzg.deserialize_g1_compressed(c)
+        assert P == _golden.g1_decompress(c) and kzg.serialize_g1_compressed(P) == c
+    assert kzg.deserialize_g1_compressed(bytes([0xC0]) + bytes(47)) is None
+    with pytest.raises(kzg.KzgError):
+        kzg.deserialize_g1_compressed(bytes(48))            # compression flag missing
+    with pytest.raises(kzg.KzgError):
+        kzg.deserialize_g1_compressed(bytes([0x9F]) + bytes([0xFF]) * 47)   # x >= p
+    n_bad = 0
+    for name, blob, com in _golden.kzg4844_raw_cases():
+        if com is None:
+            n_bad += 1
+            with pytest.raises(kzg.KzgError) as e:
+                kzg.blob_to_bigint_polynomial(blob)
+            want = (kzg.cttEthKzgStatus.cttEthKzg_InputsLengthsMismatch if len(blob) != kzg.BYTES_PER_BLOB
+                    else kzg.cttEthKzgStatus.cttEthKzg_ScalarLargerThanCurveOrder)
+            assert e.value.status == want, name
+        else:
+            poly = kzg.blob_to_bigint_polynomial(blob)
+            assert poly.shape == (4096, 32)
+            assert int.from_bytes(bytes(poly[5]), "little") == int.from_bytes(blob[160:192], "big")
+    assert n_bad == 4
+
+
+@pytest.mark.gpu
+def test_blob_to_kzg_commitment_on_gpu():
+    """blob_to_kzg_commitment (ethereum_eip4844_kzg.nim:297-330) over the GPU MSM: all reference vectors."""
+    import os
+    from constantine_amd import kzg
+    raw = open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read()
+    ctx = kzg.EthereumKZGContext(raw)
+    try:
+        for name, blob, com in _golden.kzg4844_raw_cases():
+            if com is None:
+                with pytest.raises(kzg.KzgError):
+                    kzg.blob_to_kzg_commitment(ctx, blob)
+            else:
+                assert kzg.blob_to_kzg_commitment(ctx, blob) == com, name
+    finally:
+        ctx.delete()
