@@ -8,8 +8,9 @@ Run in the build container (where /root/reference exists):
 Sources (reference-relative):
   tests/math_elliptic_curves/vectors/tv_<curve>_scalar_mul_<G1|G2>_<bits>bit.json
       -> scalar_mul_kat.json : {curve: [[P, k, Q], ...]}   (hex ints; Fp2 as [c0, c1])
-  tests/protocol_ethereum_evm_precompiles/eip-2537/multiexp_{G1,G2}_bls.json
-      -> eip2537_multiexp.json : {"g1": [[name, input_hex, expected_hex], ...], "g2": [...]}
+  tests/protocol_ethereum_evm_precompiles/eip-2537/multiexp_{G1,G2}_bls.json, fail-multiexp_{G1,G2}_bls.json
+      -> eip2537_multiexp.json : {"g1": [[name, input_hex, expected_hex], ...], "g2": [...],
+                                  "g1_fail": [[name, input_hex, expected_error], ...], "g2_fail": [...]}
 
 The GPU box has no /root/reference: tests read only the files written here.
 """
@@ -53,6 +54,8 @@ def main():
     for g in ("G1", "G2"):
         doc = json.load(open(f"{REF}/protocol_ethereum_evm_precompiles/eip-2537/multiexp_{g}_bls.json"))
         eip[g.lower()] = [[t["Name"], t["Input"], t["Expected"]] for t in doc]
+        fail = json.load(open(f"{REF}/protocol_ethereum_evm_precompiles/eip-2537/fail-multiexp_{g}_bls.json"))
+        eip[g.lower() + "_fail"] = [[t["Name"], t["Input"], t["ExpectedError"]] for t in fail]
     with open(os.path.join(HERE, "eip2537_multiexp.json"), "w") as f:
         json.dump(eip, f, separators=(",", ":"))
     print({k: len(v) for k, v in out.items()}, {k: len(v) for k, v in eip.items()})

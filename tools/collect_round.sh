@@ -1,0 +1,40 @@
+#!/bin/bash
+# Collect one round's measured evidence on the GPU box (run through gpurun from the repo root):
+#     gpurun --timeout 1500 -- 'bash tools/collect_round.sh r01'
+# Writes everything under gpurun_out/<tag>/; copy what should be judged into profiles/.
+set -u
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+REPO=$PWD
+
+timeout 600 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
+
+# headline line, un-profiled
+timeout 600 python bench.py --steps 20 --warmup 3 > "$OUT/bench_$TAG.json" 2> "$OUT/bench.err"
+
+# kernel trace + stats (rocpd database, summarised by tools/kernel_timeline.py)
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o p -- python "$REPO/bench.py" --steps 10 --warmup 2 \
+    --no-cpu-baseline > "$OUT/bench_${TAG}_under_rocprof.json" 2> "$OUT/prof.log" )
+DB=$(find "$OUT/prof" -name "*.db" | head -1)
+python tools/kernel_timeline.py "$DB" > "$OUT/rocprof_${TAG}_kernel_stats.txt" 2>> "$OUT/prof.log"
+
+# HBM traffic: one counter per pass, csv output, kernel-trace only
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o p -- python "$REPO/bench.py" \
+      --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.log" )
+done
+python tools/pmc_summary.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "bls12_381_g1_2^20" "$OUT/hbm_traffic_k_accum.json" \
+    "$OUT/pmc_${TAG}_hbm_bytes.txt" > /dev/null 2>> "$OUT/prof.log"
+
+# the other BASELINE configs and the size sweep
+timeout 300 python bench.py --curve bn254_snarks_g1 --log2n 22 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_bn254_snarks_g1.json" 2>> "$OUT/bench.err"
+timeout 300 python bench.py --curve pallas --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_pallas.json" 2>> "$OUT/bench.err"
+timeout 300 python bench.py --curve vesta --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_vesta.json" 2>> "$OUT/bench.err"
+timeout 300 python bench.py --curve bls12_381_g2 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g2.json" 2>> "$OUT/bench.err"
+for k in 16 18 22 24; do
+  timeout 300 python bench.py --log2n $k --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g1_2pow$k.json" 2>> "$OUT/bench.err"
+done
+find "$OUT/prof" -name "*.db" -delete 2>/dev/null   # the rocpd databases are large; the summaries are what is kept
+tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench_$TAG.json"
