@@ -14,6 +14,8 @@ from .msm import (  # noqa: F401
     CachedBases,
     CttEngine,
     DeviceMsm,
+    batchAffine_vartime,
+    sum_reduce_vartime,
     multiScalarMul_vartime,
     multiScalarMul_vartime_parallel,
 )

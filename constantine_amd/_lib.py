@@ -22,11 +22,28 @@ def exported_symbols():
                 syms.append(f"ctt_{stem}_{coord}_multi_scalar_mul_{coef}_coefs_vartime")
                 if par:
                     syms.append(f"ctt_{stem}_{coord}_multi_scalar_mul_{coef}_coefs_vartime_parallel")
-    syms += ["ctt_hip_msm_abi_version", "ctt_hip_msm_ctx_create", "ctt_hip_msm_ctx_destroy", "ctt_hip_msm_set_option",
+            syms.append(f"ctt_{stem}_{coord}_batch_affine")
+    syms += ["ctt_hip_sum_reduce", "ctt_hip_batch_affine", "ctt_hip_msm_abi_version", "ctt_hip_msm_ctx_create", "ctt_hip_msm_ctx_destroy", "ctt_hip_msm_set_option",
              "ctt_hip_msm_device", "ctt_hip_msm_device_submit", "ctt_hip_msm_device_finish", "ctt_hip_msm_sync", "ctt_hip_msm_bases_create", "ctt_hip_msm_bases_destroy",
              "ctt_hip_msm_with_bases", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
              "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream"]
     return syms
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 and asks for it by the unversioned name,
+    so if this library pulled in /opt/rocm's copy first, torch would load a second runtime that finds no GPU.  When
+    torch is installed, load ITS runtime first (same SONAME libamdhip64.so.7 -> our NEEDED entry binds to it)."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def lib():
@@ -37,6 +54,7 @@ def lib():
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C constantine_amd/csrc). There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
     for name in exported_symbols():
@@ -47,6 +65,13 @@ def lib():
         elif name.endswith("_vartime_parallel"):
             fn.argtypes = [vp, vp, vp, vp, sz]
             fn.restype = None
+        elif name.endswith("_batch_affine") and not name.startswith("ctt_hip"):
+            fn.argtypes = [vp, vp, sz]
+            fn.restype = None
+    L.ctt_hip_sum_reduce.argtypes = [vp, i32, i32, vp, vp, sz, i32]
+    L.ctt_hip_sum_reduce.restype = i32
+    L.ctt_hip_batch_affine.argtypes = [vp, i32, i32, vp, vp, sz, i32]
+    L.ctt_hip_batch_affine.restype = i32
     L.ctt_hip_msm_abi_version.restype = i32
     L.ctt_hip_msm_ctx_create.argtypes = [i32]
     L.ctt_hip_msm_ctx_create.restype = vp

@@ -60,6 +60,13 @@ __global__ void __launch_bounds__(EC_BLOCK) k_pyr(PyrArgs<F> a, uint32_t ntasks)
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < ntasks) pyr_body<F>(a, blockIdx.y, t);
 }
+static __global__ void k_iota(uint32_t* entries, uint32_t n, uint32_t* bucket_start, uint32_t* maxcount) {
+  iota_body(entries, n, bucket_start, maxcount, blockIdx.x * blockDim.x + threadIdx.x);
+}
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_batch_affine(BatchAffineArgs<F> a) {
+  batch_affine_body<F>(a, blockIdx.x * blockDim.x + threadIdx.x);
+}
 template <class C>
 __global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t first, uint32_t n, Affine<typename C::F>* out) {
   Affine<typename C::F> G = generator<C>();
@@ -137,6 +144,14 @@ struct HipBackend {
     HIP_CHECK(hipEventRecord(ev_done[slot], stream));
   }
   void d2h_wait(int slot) { HIP_CHECK(hipEventSynchronize(ev_done[slot])); }
+  void d2h_sync(void* dst, const void* src, size_t b) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void launch_iota(uint32_t* entries, uint32_t n, uint32_t* bucket_start, uint32_t* maxcount) {
+    hipLaunchKernelGGL(k_iota, grid1(n, 256), dim3(256), 0, stream, entries, n, bucket_start, maxcount);
+    HIP_CHECK(hipGetLastError());
+  }
   // small device->host word, overlapped with kernels launched after it
   uint32_t* h_word = nullptr;
   hipEvent_t ev_word = nullptr;
@@ -242,6 +257,11 @@ struct CurveOps {
   // host-only: r_aff = sum of n affine points (combining the per-GPU partial results of a sharded MSM,
   // the `r ~+= partial` of ec_multi_scalar_mul_parallel.nim:427-429)
   void (*ec_sum_affine)(const void* pts_aff, size_t n, void* r_host, int out_kind);
+  // r = sum of n affine points resident on the device (sum_reduce_vartime); returns the K used
+  int (*sum_reduce)(void* eng, const MsmOptions* opt, const void* d_points, uint32_t n, void* r_host, int out_kind);
+  // dst[i] = affine(src[i]) for n Jacobian (src_kind 1) or projective (2) points, device memory, K points per lane
+  void (*batch_affine)(HipBackend* bk, int src_kind, void* d_dst, const void* d_src, uint32_t n, uint32_t K);
+  size_t fe_bytes;  // one coordinate
 };
 
 template <class C>
@@ -323,8 +343,24 @@ struct CurveImpl {
     for (size_t i = 0; i < n; i++) xyzz_madd<HF>(acc, p[i], false);
     write_result<HF>(r_host, acc, out_kind);
   }
+  static int sum_reduce(void* eng, const MsmOptions* opt, const void* d_points, uint32_t n, void* r_host, int out_kind) {
+    Engine& e = *(Engine*)eng;
+    uint32_t lanes = e.opt.lanes;
+    e.opt = *opt;
+    e.opt.lanes = lanes;
+    auto res = e.sum_reduce((const Affine<F>*)d_points, n);
+    write_result<typename Engine::HF>(r_host, res, out_kind);
+    return (int)e.last_sum_K;
+  }
+  static void batch_affine(HipBackend* bk, int src_kind, void* d_dst, const void* d_src, uint32_t n, uint32_t K) {
+    if (n == 0) return;
+    BatchAffineArgs<F> a{(const F*)d_src, (Affine<F>*)d_dst, n, src_kind, K};
+    const uint32_t lanes = (n + K - 1) / K;
+    hipLaunchKernelGGL(k_batch_affine<F>, dim3((lanes + EC_BLOCK - 1) / EC_BLOCK), dim3(EC_BLOCK), 0, bk->stream, a);
+    HIP_CHECK(hipGetLastError());
+  }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, run, submit, finish, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, run, submit, finish, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F)};
     return &o;
   }
 };

@@ -352,6 +352,72 @@ CTT_HD void pyr_body(const PyrArgs<F>& a, uint32_t w, uint32_t t) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// sum_reduce (ec_shortweierstrass_batch_ops.nim:649-663): every point belongs to ONE bucket, so the bucket
+// accumulation and head-merging kernels above do the whole job; this body only writes the trivial "sort" result
+// (identity entry list, bucket_start = {0, n}, largest bucket = n).
+// ---------------------------------------------------------------------------------------------
+CTT_HD void iota_body(uint32_t* entries, uint32_t n, uint32_t* bucket_start, uint32_t* maxcount, uint32_t j) {
+  if (j == 0) {
+    bucket_start[0] = 0;
+    bucket_start[1] = n;
+    *maxcount = n;
+  }
+  if (j < n) entries[j] = j;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batchAffine (ec_shortweierstrass_batch_ops.nim:44-106 Prj, :108-178 Jac, vartime twins :187-345):
+// Montgomery's simultaneous inversion.  One lane owns K consecutive points and one inversion; like the reference
+// it parks the running products in dst[i].x, so no scratch memory is needed.  Neutral inputs (Z = 0) are skipped
+// in the product chain and come out as the affine neutral (0,0).
+// ---------------------------------------------------------------------------------------------
+enum { SRC_JAC = 1, SRC_PRJ = 2 };
+
+template <class F>
+struct BatchAffineArgs {
+  const F* src;     // [n][3]  X, Y, Z
+  Affine<F>* dst;   // [n]
+  uint32_t n;
+  int kind;         // SRC_JAC: x = X/Z^2, y = Y/Z^3 ; SRC_PRJ: x = X/Z, y = Y/Z
+  uint32_t K;       // points per lane
+};
+
+template <class F>
+CTT_HD void batch_affine_body(const BatchAffineArgs<F>& a, uint32_t lane) {
+  const uint64_t i0 = (uint64_t)lane * a.K;
+  if (i0 >= a.n) return;
+  const uint64_t i1 = (i0 + a.K < a.n) ? i0 + a.K : a.n;
+  F run = F::one();
+  for (uint64_t i = i0; i < i1; i++) {
+    F z = a.src[3 * i + 2];
+    if (!z.is_zero()) run = F::mul(run, z);
+    a.dst[i].x = run;
+  }
+  F inv = F::inv(run);
+  for (uint64_t i = i1; i-- > i0;) {
+    F z = a.src[3 * i + 2];
+    if (z.is_zero()) {
+      a.dst[i] = Affine<F>::inf();
+      continue;
+    }
+    F prev = (i > i0) ? a.dst[i - 1].x : F::one();
+    F zi = F::mul(inv, prev);  // 1 / z_i
+    inv = F::mul(inv, z);
+    F X = a.src[3 * i], Y = a.src[3 * i + 1];
+    Affine<F> o;
+    if (a.kind == SRC_JAC) {
+      F zi2 = F::sqr(zi);
+      o.x = F::mul(X, zi2);
+      o.y = F::mul(Y, F::mul(zi2, zi));
+    } else {
+      o.x = F::mul(X, zi);
+      o.y = F::mul(Y, zi);
+    }
+    a.dst[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic subgroup points for benchmarks/tests: P_i = [s_i]G, s_i = 128-bit splitmix word pair | 1
 // (same definition as oracle/pyoracle.py synth_point; mirrors the distribution of the reference's
 // bench inputs, benchmarks/bench_elliptic_parallel_template.nim:78-102)

@@ -296,6 +296,50 @@ struct MsmEngine {
   XYZZ<HF> run(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n) {
     return finish(submit(d_coefs, coef_is_fr, d_points_in, n));
   }
+
+  // r = sum of n affine points (sum_reduce_vartime, ec_shortweierstrass_batch_ops.nim:649-663).  One window, one
+  // bucket: the identity entry list goes through the accumulate kernel (K points per lane) and the head-merging
+  // tree; blocking.  Shares the MSM workspace (stream order keeps it apart from MSMs in flight).
+  uint32_t last_sum_K = 0;
+  XYZZ<HF> sum_reduce(const Affine<F>* d_points_in, uint32_t n) {
+    if (n == 0) return XYZZ<HF>::inf();
+    const uint32_t lanes = opt.lanes ? opt.lanes : 65536;
+    uint32_t K = (uint32_t)(((uint64_t)n + lanes - 1) / lanes);
+    if (K < 16) K = 16;
+    if (opt.K > 0) K = (uint32_t)opt.K;
+    const uint32_t G = (n + K - 1) / K;
+    last_sum_K = K;
+    const void* d_points;
+    uint32_t point_stride;
+    if constexpr (kConvert) {
+      void* cp = need(cpoints, (size_t)n * gather_stride<FD>());
+      bk.template launch_convert<F, FD>(d_points_in, cp, n);
+      d_points = cp;
+      point_stride = gather_stride<FD>();
+    } else {
+      d_points = (const void*)d_points_in;
+      point_stride = (uint32_t)sizeof(Affine<F>);
+    }
+    uint32_t* d_entries = (uint32_t*)need(entries, (size_t)n * 4);
+    uint32_t* d_bstart = (uint32_t*)need(bstart, 8);
+    uint32_t* d_maxcount = (uint32_t*)need(maxcount, 256);
+    bk.launch_iota(d_entries, n, d_bstart, d_maxcount);
+    XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(buckets, sizeof(XYZZ<FD>));
+    bk.memset0(d_buckets, sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_heads = (XYZZ<FD>*)need(heads, (size_t)G * sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_tails = (XYZZ<FD>*)need(tails, (size_t)G * sizeof(XYZZ<FD>));
+    uint32_t* d_hkey = (uint32_t*)need(hkey, (size_t)G * 4);
+    uint32_t* d_tkey = (uint32_t*)need(tkey, (size_t)G * 4);
+    AccumArgs<FD> aa{d_entries, d_bstart, d_points, point_stride, d_buckets, d_heads, d_tails, d_hkey, d_tkey, n, 1, K, G};
+    bk.template launch_accum<FD>(aa, 1);
+    MergeArgs<FD> ma{d_bstart, d_buckets, d_heads, d_tails, d_hkey, d_tkey, d_maxcount, 1, K, G};
+    bk.template launch_merge_tail<FD>(ma, 1);
+    for (uint32_t d = 1; d < G; d <<= 1) bk.template launch_merge_step<FD>(ma, 1, d);
+    bk.template launch_merge_final<FD>(ma, 1);
+    XYZZ<FD> raw;
+    bk.d2h_sync(&raw, d_buckets, sizeof(raw));
+    return xyzz_to_host<FD>(raw);
+  }
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -130,6 +130,21 @@ class DeviceMsm:
         if rc != 0:
             raise RuntimeError("ctt_hip_field_op failed")
 
+    def sum_reduce(self, curve, d_points, n, coord="aff"):
+        """r = sum of n affine points resident in HBM (sum_reduce_vartime)."""
+        info = CURVES[curve]
+        nco = 2 if coord == "aff" else 3
+        r = np.zeros(nco * info.coord_bytes, dtype=np.uint8)
+        if self.L.ctt_hip_sum_reduce(self.ctx, info.cid, _COORD[coord], _ptr(r), self._dptr(d_points), n, 1) != 0:
+            raise RuntimeError("ctt_hip_sum_reduce failed")
+        return r
+
+    def batch_affine(self, curve, d_dst, d_src, n, src_coord="jac"):
+        """d_dst[i] = affine(d_src[i]); both in HBM (batchAffine_vartime)."""
+        if self.L.ctt_hip_batch_affine(self.ctx, CURVES[curve].cid, _COORD[src_coord], self._dptr(d_dst),
+                                       self._dptr(d_src), n, 1) != 0:
+            raise RuntimeError("ctt_hip_batch_affine failed")
+
     def last_timings(self):
         ms = np.zeros(6, dtype=np.float32)
         self.L.ctt_hip_msm_last_timings(self.ctx, _ptr(ms), 6)
@@ -151,6 +166,28 @@ def ec_sum_affine(curve, pts_aff, coord="aff"):
     if rc != 0:
         raise RuntimeError("ctt_hip_ec_sum_affine failed")
     return r
+
+
+def sum_reduce_vartime(curve, points, coord="jac"):
+    """Mirror of sum_reduce_vartime(r, points) (ec_shortweierstrass_batch_ops.nim:649-663), host arrays in, GPU sum."""
+    info = CURVES[curve]
+    pts = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, info.aff_bytes)
+    nco = 2 if coord == "aff" else 3
+    r = np.zeros(nco * info.coord_bytes, dtype=np.uint8)
+    if _lib.lib().ctt_hip_sum_reduce(None, info.cid, _COORD[coord], _ptr(r), _ptr(pts), pts.shape[0], 0) != 0:
+        raise RuntimeError("ctt_hip_sum_reduce failed")
+    return r
+
+
+def batchAffine_vartime(curve, points, coord="jac"):
+    """Mirror of batchAffine_vartime(affs, projs) through the Constantine C symbol `ctt_<curve>_<coord>_batch_affine`
+    (bindings/c_curve_decls.nim:395-396): [n][3 coordinates] Montgomery bytes -> [n] affine points."""
+    info = CURVES[curve]
+    src = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 3 * info.coord_bytes)
+    dst = np.zeros((src.shape[0], info.aff_bytes), dtype=np.uint8)
+    fn = getattr(_lib.lib(), f"ctt_{info.sym}_{coord}_batch_affine")
+    fn(_ptr(dst), _ptr(src), src.shape[0])
+    return dst
 
 
 class CachedBases:

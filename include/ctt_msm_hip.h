@@ -112,6 +112,23 @@ CTT_MSM_DECL_SERIAL(vesta_ec_prj, vesta_ec_aff, big255, vesta_fr)
 CTT_MSM_DECL_PARALLEL(vesta_ec_jac, vesta_ec_aff, big255, vesta_fr)
 CTT_MSM_DECL_PARALLEL(vesta_ec_prj, vesta_ec_aff, big255, vesta_fr)
 
+/* ---- Part 1b: Constantine-compatible batch conversion to affine (next row) -----------
+ * bindings/c_curve_decls.nim:395-396 (`ctt_<EC>_batch_affine`); bls12_381.h:158,179,207,228, bn254_snarks.h:158,179,
+ * 207,228, pallas.h:120,141, vesta.h:120,141.  dst[i] = affine(src[i]); a neutral input gives (0,0).  Host pointers. */
+#define CTT_BATCH_AFFINE_DECL(EC, AFF) void ctt_##EC##_batch_affine(AFF dst[], const EC src[], size_t n);
+CTT_BATCH_AFFINE_DECL(bls12_381_g1_jac, bls12_381_g1_aff)
+CTT_BATCH_AFFINE_DECL(bls12_381_g1_prj, bls12_381_g1_aff)
+CTT_BATCH_AFFINE_DECL(bls12_381_g2_jac, bls12_381_g2_aff)
+CTT_BATCH_AFFINE_DECL(bls12_381_g2_prj, bls12_381_g2_aff)
+CTT_BATCH_AFFINE_DECL(bn254_snarks_g1_jac, bn254_snarks_g1_aff)
+CTT_BATCH_AFFINE_DECL(bn254_snarks_g1_prj, bn254_snarks_g1_aff)
+CTT_BATCH_AFFINE_DECL(bn254_snarks_g2_jac, bn254_snarks_g2_aff)
+CTT_BATCH_AFFINE_DECL(bn254_snarks_g2_prj, bn254_snarks_g2_aff)
+CTT_BATCH_AFFINE_DECL(pallas_ec_jac, pallas_ec_aff)
+CTT_BATCH_AFFINE_DECL(pallas_ec_prj, pallas_ec_aff)
+CTT_BATCH_AFFINE_DECL(vesta_ec_jac, vesta_ec_aff)
+CTT_BATCH_AFFINE_DECL(vesta_ec_prj, vesta_ec_aff)
+
 /* ---- Part 2: device-resident interface ------------------------------------------------------------------ */
 typedef struct ctt_hip_msm_ctx ctt_hip_msm_ctx;
 
@@ -163,6 +180,14 @@ int ctt_hip_field_op(ctt_hip_msm_ctx* ctx, int curve, int op, const void* d_a, c
 /* host-only: r (`out_kind` layout) = sum of n affine points -- combines the per-GPU partial results of a
  * sharded MSM (the `r ~+= partial` of ec_multi_scalar_mul_parallel.nim:427-429). Needs no GPU. */
 int ctt_hip_ec_sum_affine(int curve, int out_kind, void* r, const void* pts_aff, size_t n);
+/* r (host, `out_kind` layout) = sum of `len` affine points -- sum_reduce_vartime
+ * (ec_shortweierstrass_batch_ops.nim:649-663) on the GPU; points on the host (points_on_device = 0) or in HBM (1). */
+int ctt_hip_sum_reduce(ctt_hip_msm_ctx* ctx, int curve, int out_kind, void* r, const void* points, size_t len,
+                       int points_on_device);
+/* dst[i] = affine(src[i]), src_kind CTT_HIP_OUT_JAC (x = X/Z^2, y = Y/Z^3) or CTT_HIP_OUT_PRJ (x = X/Z, y = Y/Z) --
+ * batchAffine(_vartime) (ec_shortweierstrass_batch_ops.nim:44-345).  Both arrays on the host (on_device = 0) or both
+ * in HBM (1).  Blocking. */
+int ctt_hip_batch_affine(ctt_hip_msm_ctx* ctx, int curve, int src_kind, void* dst, const void* src, size_t n, int on_device);
 /* the engine's hipStream_t */
 void* ctt_hip_msm_stream(ctt_hip_msm_ctx* ctx);
 

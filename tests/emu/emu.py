@@ -28,6 +28,8 @@ def lib():
         L.emu_field_op.argtypes = [i32, i32, vp, vp, vp]
         L.emu_field_op_dev.argtypes = [i32, i32, vp, vp, vp]
         L.emu_dev_field_info.argtypes = [i32, vp, vp]
+        L.emu_sum_reduce.argtypes = [i32, i32, vp, vp, sz, i32]
+        L.emu_batch_affine.argtypes = [i32, i32, vp, vp, sz, i32]
         _lib = L
     return _lib
 
@@ -76,3 +78,20 @@ def field_op_dev(curve, op, a, b=None):
     out = np.zeros(64, dtype=np.uint32)
     nl = lib().emu_field_op_dev(CURVE_ID[curve], op, _p(a), _p(b), _p(out))
     return out[:nl]
+
+
+def sum_reduce(curve, points, out_kind=0, K=0):
+    points = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, AFF_BYTES[curve])
+    nco = 2 if out_kind == 0 else 3
+    out = np.zeros(AFF_BYTES[curve] // 2 * nco, dtype=np.uint8)
+    k = lib().emu_sum_reduce(CURVE_ID[curve], out_kind, _p(out), _p(points), points.shape[0], K)
+    assert k >= 0
+    return out
+
+
+def batch_affine(curve, src, src_kind=1, K=8):
+    """src: [n][3 coordinates] Jacobian (src_kind 1) or projective (2) -> [n] affine."""
+    src = np.ascontiguousarray(src, dtype=np.uint8).reshape(-1, AFF_BYTES[curve] // 2 * 3)
+    out = np.zeros((src.shape[0], AFF_BYTES[curve]), dtype=np.uint8)
+    assert lib().emu_batch_affine(CURVE_ID[curve], src_kind, _p(out), _p(src), src.shape[0], K) == 0
+    return out

@@ -21,6 +21,10 @@ struct EmuBackend {
   void free_host(void* p) { ::free(p); }
   void d2h_async(int, void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void d2h_wait(int) {}
+  void d2h_sync(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
+  void launch_iota(uint32_t* entries, uint32_t n, uint32_t* bstart, uint32_t* maxcount) {
+    for (uint32_t j = 0; j < (n ? n : 1); j++) iota_body(entries, n, bstart, maxcount, j);
+  }
   uint32_t word = 0;
   void fetch_u32_async(const uint32_t* d) { word = *d; }
   uint32_t fetch_u32_wait() { return word; }
@@ -113,6 +117,8 @@ struct EmuOps {
   void (*fop)(int op, const void* a, const void* b, void* r);
   int (*fop_dev)(int op, const void* a, const void* b, void* r);
   int (*dev_info)(int* lb, int* nl);
+  int (*sum_reduce)(int out_kind, void* r, const void* points, size_t n, int K);
+  void (*batch_affine)(int src_kind, void* dst, const void* src, size_t n, int K);
 };
 
 #ifdef EMU_CURVE
@@ -190,8 +196,21 @@ struct EmuCurve {
     }
     return 0;
   }
+  static int sum_reduce(int out_kind, void* r, const void* points, size_t n, int K) {
+    EmuBackend bk;
+    MsmEngine<C, EmuBackend> eng(bk);
+    eng.opt.K = K;
+    eng.opt.lanes = 64;
+    auto res = eng.sum_reduce((const Affine<F>*)points, (uint32_t)n);
+    write_result<typename MsmEngine<C, EmuBackend>::HF>(r, res, out_kind);
+    return (int)eng.last_sum_K;
+  }
+  static void batch_affine(int src_kind, void* dst, const void* src, size_t n, int K) {
+    BatchAffineArgs<F> a{(const F*)src, (Affine<F>*)dst, (uint32_t)n, src_kind, (uint32_t)K};
+    for (uint32_t lane = 0; (uint64_t)lane * K < n; lane++) batch_affine_body<F>(a, lane);
+  }
   static const EmuOps* ops() {
-    static const EmuOps o = {msm, gen, fop, fop_dev, dev_info};
+    static const EmuOps o = {msm, gen, fop, fop_dev, dev_info, sum_reduce, batch_affine};
     return &o;
   }
 };
@@ -252,6 +271,16 @@ int emu_field_op(int curve, int op, const void* a, const void* b, void* r) {
 int emu_field_op_dev(int curve, int op, const void* a, const void* b, void* r) {
   const EmuOps* o = ops_of(curve);
   return o ? o->fop_dev(op, a, b, r) : 0;
+}
+int emu_sum_reduce(int curve, int out_kind, void* r, const void* points, size_t n, int K) {
+  const EmuOps* o = ops_of(curve);
+  return o ? o->sum_reduce(out_kind, r, points, n, K) : -1;
+}
+int emu_batch_affine(int curve, int src_kind, void* dst, const void* src, size_t n, int K) {
+  const EmuOps* o = ops_of(curve);
+  if (!o) return -1;
+  o->batch_affine(src_kind, dst, src, n, K);
+  return 0;
 }
 int emu_dev_field_info(int curve, int* lb, int* nl) {
   const EmuOps* o = ops_of(curve);

@@ -42,7 +42,8 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.ctt_hip_msm_abi_version() == 1
+    assert len([s for s in declared if s.endswith('_batch_affine') and 'hip' not in s]) == 12
+    assert L.ctt_hip_msm_abi_version() == 2
 
 
 def test_host_only_point_sum_matches_oracle():

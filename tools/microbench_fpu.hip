@@ -75,6 +75,63 @@ __device__ __forceinline__ FU mul_four_acc(const FU& a, const FU& b) {
   return t;
 }
 
+// variant S: 13 signed 30-bit limbs (390-bit radix), v_mad_i64_i32 accumulation; 338 multiplies instead of 392.
+// Throughput experiment only (round-2 candidate representation for BLS12-381).
+constexpr int NS = 13, SB = 30;
+struct FS { int32_t l[NS]; };
+__device__ constexpr int32_t PS[NS] = {-21845, -402915328, 356515836, -352321620, -252304353, 55215067, 288093811,
+                                       316751073, -321428361, 517541167, -375082566, -91332614, 1704210};
+constexpr uint32_t PS_M0INV = 1073545213u;
+__device__ __forceinline__ int32_t sext30(uint32_t x) { return (int32_t)(x << 2) >> 2; }
+__device__ __forceinline__ FS mul_signed13(const FS& a, const FS& b) {
+  int64_t carry = 0;
+  int32_t m[NS];
+  FS t;
+#pragma unroll
+  for (int k = 0; k < 2 * NS - 1; k++) {
+    int64_t acc = carry;
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < NS) acc += (int64_t)a.l[i] * b.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      const int j = k - i;
+      if (j >= 1 && j < NS && i < (k < NS ? k : NS)) acc += (int64_t)m[i] * PS[j];
+    }
+    if (k < NS) {
+      m[k] = sext30((uint32_t)acc * PS_M0INV);
+      acc += (int64_t)m[k] * PS[0];
+      carry = acc >> SB;
+    } else {
+      int32_t d = sext30((uint32_t)acc);
+      t.l[k - NS] = d;
+      carry = (acc - d) >> SB;
+    }
+  }
+  t.l[NS - 1] = (int32_t)carry;
+  return t;
+}
+
+template <int V>
+__global__ void k_chain_s(uint32_t* out, uint32_t seed, int iters) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  FS a, b;
+  for (int i = 0; i < NS; i++) {
+    a.l[i] = sext30(tid * 2654435761u + i * 40503u + seed) >> 1;
+    b.l[i] = sext30(tid * 2246822519u + i * 69069u + seed * 3u) >> 1;
+  }
+  const FS a0 = a, b0 = b;
+  for (int i = 0; i < iters; i++) {
+    if (V == 0) a = mul_signed13(a, b);
+    if (V == 1) { FS c = mul_signed13(a, a0); b = mul_signed13(b, b0); a = c; }
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < NS; i++) s ^= (uint32_t)a.l[i] ^ (uint32_t)b.l[i];
+  out[tid] = s;
+}
+
 template <int V>
 __global__ void k_chain(uint32_t* out, uint32_t seed, int iters) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,6 +193,10 @@ int main() {
     t[5] = time_kernel(k_chain<5>, nb, 256, out, iters) / 2;
     t[6] = time_kernel(k_chain<6>, nb, 256, out, iters) / 2;
     t[7] = time_kernel(k_chain<7>, nb, 256, out, iters);
+    printf("{\"field_op\": \"signed13x30_mul\", \"waves_per_simd\": %d, \"Gops_per_s\": %.2f}\n", wps,
+           (double)nb * 256 * iters / time_kernel(k_chain_s<0>, nb, 256, out, iters) / 1e9);
+    printf("{\"field_op\": \"signed13x30_mul_x2_independent\", \"waves_per_simd\": %d, \"Gops_per_s\": %.2f}\n", wps,
+           (double)nb * 256 * iters * 2 / time_kernel(k_chain_s<1>, nb, 256, out, iters) / 1e9);
     for (int v = 0; v < 8; v++)
       printf("{\"field_op\": \"%s\", \"waves_per_simd\": %d, \"Gops_per_s\": %.2f}\n", names[v], wps,
              (double)nb * 256 * iters / t[v] / 1e9);
