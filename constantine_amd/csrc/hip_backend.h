@@ -202,9 +202,7 @@ struct HipBackend {
     hipLaunchKernelGGL((k_convert_points<F, FD>), grid1(n, 256), dim3(256), 0, stream, in, out, n);
     HIP_CHECK(hipGetLastError());
   }
-  void launch_digits(const DigitsArgs& a);  // msm_engine.hip
-  void launch_sort(const uint32_t* digits, uint32_t* counts, uint32_t* totals, uint32_t* bstart, uint32_t* entries,
-                   uint32_t* maxcount, uint32_t n, uint32_t B, uint32_t S, uint32_t slice, uint32_t W);  // msm_engine.hip
+  void launch_digits_sort(const SortArgs& a);  // msm_engine.hip
   template <class F>
   void launch_accum(const AccumArgs<F>& a, uint32_t W) {
     hipLaunchKernelGGL(k_accum<F>, grid2(a.G, ACCUM_BLOCK, W), dim3(ACCUM_BLOCK), 0, stream, a);

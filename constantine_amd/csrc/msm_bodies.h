@@ -77,6 +77,29 @@ CTT_HD void digits_body(const DigitsArgs& a, uint32_t j) {
   for (int w = 0; w < a.W; w++) a.digits[(uint64_t)w * a.N + j] = booth_digit_packed(k, w, a.c);
 }
 
+// Digits + sort by bucket.  Output contract (what the accumulation consumes): for every window w,
+// entries[w][0..bucket_start[w][B]) = (point index | sign << 31) of every non-zero digit, grouped by bucket in
+// increasing bucket order (any order inside a bucket), bucket_start[w][b] = first position of bucket b, and
+// maxcount[0] = size of the largest bucket over all windows.
+struct SortArgs {
+  const uint32_t* scalars;  // [n][8] canonical
+  uint32_t n;
+  int c;
+  uint32_t W, B;
+  uint32_t NG, gshift;      // bucket groups per window; group = bucket >> gshift
+  uint32_t gshift_top;      // same for the top window W-1, whose digits only reach 2^(bits - (W-1)c) buckets
+  uint32_t slice, nblk;     // partition pass: scalars per block, number of blocks
+  uint32_t jbits;           // bits of a point index: record = low bucket bits << (jbits+1) | sign << jbits | index
+  uint32_t* part;           // [W][n] packed records partitioned by group
+  uint32_t* cntA;           // [nblk][W*NG] per-block group counts -> block offsets inside the group
+  uint32_t* gtot;           // [W*NG] group sizes
+  uint32_t* gbase;          // [W][NG+1] group start inside the window
+  uint32_t* bstart;         // [W][B+1]
+  uint32_t* entries;        // [W][n]
+  uint32_t* maxcount;       // [2]: largest bucket; scratch word
+  uint32_t cap, big;        // k_group_sort: entries per LDS tile; buckets above `big` bypass the LDS image
+};
+
 // Fr Montgomery -> canonical (batchFromField, finite_fields.nim:915-920)
 template <class Fr>
 CTT_HD void fr_from_mont_body(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t j) {

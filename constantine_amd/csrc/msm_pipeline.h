@@ -17,8 +17,13 @@ struct MsmPlan {
   uint32_t n;
   int c, W;
   uint32_t B;      // buckets per window = 2^(c-1)
-  uint32_t S;      // sort slices per window
-  uint32_t slice;  // scalars per slice
+  uint32_t S;      // partition blocks (sort pass A): each handles `slice` consecutive scalars
+  uint32_t slice;  // scalars per partition block
+  uint32_t NG;     // bucket groups per window (sort pass A partitions by group, pass B sorts inside a group)
+  uint32_t gshift; // group = bucket >> gshift
+  uint32_t gshift_top;  // the top window only reaches 2^tb buckets (tb = bits - (W-1)c): its groups are narrower
+  uint32_t jbits;  // bits of a point index (sort records pack low bucket bits | sign | index into 32 bits)
+  uint32_t cap, big;  // sort pass B: LDS tile entries; bucket size above which the LDS image is bypassed
   uint32_t K;      // sorted entries per accumulate lane
   uint32_t G;      // accumulate lanes per window
 };
@@ -26,7 +31,7 @@ struct MsmPlan {
 struct MsmOptions {
   int c = 0;          // window bits (0 = choose)
   int K = 0;          // entries per lane (0 = choose from resident lanes)
-  int S = 0;          // sort slices (0 = choose)
+  int S = 0;          // sort: scalars per partition block (0 = choose)
   uint32_t lanes = 196608;  // resident lanes of the accumulate kernel (set by the backend)
 };
 
@@ -79,13 +84,37 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   if (p.c > 16) p.c = 16;
   p.W = bits / p.c + 1;  // ec_multi_scalar_mul_parallel.nim:157-158: one more window when c | bits
   p.B = 1u << (p.c - 1);
-  // sort slices: 32 per window (one window occupies the 32 CUs of one XCD), slices of at least 4096 scalars
-  uint32_t S = o.S > 0 ? (uint32_t)o.S : 32u;
-  uint32_t maxS = (n + 4095u) / 4096u;
-  if (S > maxS) S = maxS;
-  if (S < 1) S = 1;
-  p.S = S;
-  p.slice = (n + S - 1) / S;
+  // sort pass A: ~512 partition blocks of at least 2048 scalars; pass B: groups of ~16384 entries (one workgroup
+  // sorts a group inside LDS), at most 4096 buckets per group (LDS counters)
+  static const uint32_t slenv = getenv("CTT_SORT_SLICE") ? (uint32_t)atoi(getenv("CTT_SORT_SLICE")) : 2048u;
+  uint32_t slice = o.S > 0 ? (uint32_t)o.S : slenv;
+  while (o.S <= 0 && (uint64_t)slice * 512u < n) slice <<= 1;
+  p.slice = slice;
+  p.S = (n + slice - 1) / slice;
+  p.jbits = 1;
+  while (p.jbits < 31 && (1ull << p.jbits) < n) p.jbits++;
+  // groups of ~16384 entries (k_group_sort holds one in LDS), at most 1024 buckets per group, and the packed
+  // record (low bucket bits | sign | index) must fit 32 bits
+  static const uint32_t gsz = getenv("CTT_SORT_GROUP") ? (uint32_t)atoi(getenv("CTT_SORT_GROUP")) : 16384u;
+  static const uint32_t capenv = getenv("CTT_SORT_CAP") ? (uint32_t)atoi(getenv("CTT_SORT_CAP")) : 20480u;
+  static const uint32_t bigenv = getenv("CTT_SORT_BIG") ? (uint32_t)atoi(getenv("CTT_SORT_BIG")) : 1024u;
+  p.cap = capenv;
+  p.big = bigenv;
+  uint32_t NG = 1;
+  while ((uint64_t)NG * gsz < n) NG <<= 1;
+  while (NG < p.B && p.B / NG > 1024u) NG <<= 1;
+  if (NG > p.B) NG = p.B;
+  p.gshift = 0;
+  while ((p.B >> p.gshift) > NG) p.gshift++;
+  while (p.gshift > 0 && p.jbits + 1 + p.gshift > 32) { p.gshift--; NG <<= 1; }
+  p.NG = NG;
+  {
+    const uint32_t tb = (uint32_t)(bits - (p.W - 1) * p.c);  // significant bits of the top window, 0 .. c-1
+    uint32_t lg = 0;
+    while ((1u << lg) < NG) lg++;
+    p.gshift_top = tb > lg ? tb - lg : 0u;
+    if (p.gshift_top > p.gshift) p.gshift_top = p.gshift;
+  }
   // entries per lane: fill the resident lanes once
   uint32_t K = o.K > 0 ? (uint32_t)o.K : plan_entries_per_lane(n, p.W, o.lanes);
   K = (K + 3u) & ~3u;
@@ -126,11 +155,11 @@ struct MsmEngine {
 
   // grow-only workspace
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf digits, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcount, cpoints, totals;
+  Buf part, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcount, cpoints, totals, gbase;
 
   explicit MsmEngine(BK& b) : bk(b) {}
   ~MsmEngine() {
-    Buf* all[] = {&digits, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount, &cpoints, &totals};
+    Buf* all[] = {&part, &gbase, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount, &cpoints, &totals};
     for (Buf* b : all) if (b->p) bk.free(b->p);
     for (Slot& sl : slots) if (sl.hraw) bk.free_host(sl.hraw);
   }
@@ -217,19 +246,26 @@ struct MsmEngine {
       d_points = d_prepared ? d_prepared : (const void*)d_points_in;
       point_stride = (uint32_t)sizeof(Affine<F>);
     }
-    uint32_t* d_digits = (uint32_t*)need(digits, (size_t)W * n * 4);
-    DigitsArgs da{d_scalars, d_digits, n, p.c, (int)W};
-    bk.launch_digits(da);
     bk.stage_end(sl, ST_DIGITS);
 
+    // Booth digits + sort by bucket (two passes: partition by bucket group, then sort each group inside LDS)
     bk.stage_begin(sl, ST_SORT);
-    uint32_t* d_counts = (uint32_t*)need(counts, (size_t)W * p.S * B * 4);
+    SortArgs sa;
+    sa.scalars = d_scalars;
+    sa.n = n; sa.c = p.c; sa.W = W; sa.B = B;
+    sa.NG = p.NG; sa.gshift = p.gshift; sa.gshift_top = p.gshift_top; sa.slice = p.slice; sa.nblk = p.S;
+    sa.jbits = p.jbits;
+    sa.cap = p.cap; sa.big = p.big;
+    sa.part = (uint32_t*)need(part, (size_t)W * n * 4);
+    sa.cntA = (uint32_t*)need(counts, (size_t)p.S * W * p.NG * 4);
+    sa.gtot = (uint32_t*)need(totals, (size_t)W * p.NG * 4);
+    sa.gbase = (uint32_t*)need(gbase, (size_t)W * (p.NG + 1) * 4);
     uint32_t* d_bstart = (uint32_t*)need(bstart, (size_t)W * (B + 1) * 4);
     uint32_t* d_entries = (uint32_t*)need(entries, (size_t)W * n * 4);
     uint32_t* d_maxcount = (uint32_t*)need(maxcount, 256);
-    bk.memset0(d_maxcount, 4);
-    uint32_t* d_totals = (uint32_t*)need(totals, (size_t)W * B * 4);
-    bk.launch_sort(d_digits, d_counts, d_totals, d_bstart, d_entries, d_maxcount, n, B, p.S, p.slice, W);
+    bk.memset0(d_maxcount, 8);
+    sa.bstart = d_bstart; sa.entries = d_entries; sa.maxcount = d_maxcount;
+    bk.launch_digits_sort(sa);
     bk.fetch_u32_async(d_maxcount);  // largest bucket: read back while the accumulation runs
     bk.stage_end(sl, ST_SORT);
 

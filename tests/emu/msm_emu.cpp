@@ -39,48 +39,29 @@ struct EmuBackend {
   void launch_convert(const Affine<F>* in, void* out, uint32_t n) {
     for (uint32_t j = 0; j < n; j++) convert_point_body<F, FD>(in, out, n, j);
   }
-  void launch_digits(const DigitsArgs& a) {
-    for (uint32_t j = 0; j < a.N; j++) digits_body(a, j);
-  }
-  void launch_sort(const uint32_t* digits, uint32_t* counts, uint32_t* /*totals*/, uint32_t* bstart, uint32_t* entries,
-                   uint32_t* maxcount, uint32_t n, uint32_t B, uint32_t S, uint32_t slice, uint32_t W) {
-    for (uint32_t w = 0; w < W; w++) {
-      // hist
-      for (uint32_t s = 0; s < S; s++) {
-        uint32_t* h = counts + ((size_t)w * S + s) * B;
-        memset(h, 0, (size_t)B * 4);
-        uint32_t j1 = std::min(n, (s + 1) * slice);
-        for (uint32_t j = s * slice; j < j1; j++) {
-          uint32_t d = digits[(size_t)w * n + j];
-          if (d != DIGIT_NONE) h[d >> 1]++;
-        }
+  // digits + sort: only the output contract of SortArgs is emulated (the GPU's two-pass LDS sort is exercised by
+  // the GPU parity tests); plain counting sort per window
+  void launch_digits_sort(const SortArgs& a) {
+    const uint32_t n = a.n, B = a.B;
+    std::vector<uint32_t> dg(n), cnt(B);
+    *a.maxcount = 0;
+    for (uint32_t w = 0; w < a.W; w++) {
+      std::fill(cnt.begin(), cnt.end(), 0u);
+      for (uint32_t j = 0; j < n; j++) {
+        dg[j] = booth_digit_packed(a.scalars + 8ull * j, (int)w, a.c);
+        if (dg[j] != DIGIT_NONE) cnt[dg[j] >> 1]++;
       }
-      // scan
-      uint32_t run = 0, mx = 0;
+      uint32_t* bs = a.bstart + (size_t)w * (B + 1);
+      uint32_t run = 0;
       for (uint32_t b = 0; b < B; b++) {
-        uint32_t tot = 0;
-        for (uint32_t s = 0; s < S; s++) {
-          uint32_t* p = counts + ((size_t)w * S + s) * B + b;
-          uint32_t v = *p;
-          *p = tot;
-          tot += v;
-        }
-        bstart[(size_t)w * (B + 1) + b] = run;
-        run += tot;
-        mx = std::max(mx, tot);
+        bs[b] = run;
+        run += cnt[b];
+        *a.maxcount = std::max(*a.maxcount, cnt[b]);
       }
-      bstart[(size_t)w * (B + 1) + B] = run;
-      *maxcount = std::max(*maxcount, mx);
-      // scatter
-      for (uint32_t s = 0; s < S; s++) {
-        std::vector<uint32_t> off(B);
-        for (uint32_t b = 0; b < B; b++) off[b] = counts[((size_t)w * S + s) * B + b] + bstart[(size_t)w * (B + 1) + b];
-        uint32_t j1 = std::min(n, (s + 1) * slice);
-        for (uint32_t j = s * slice; j < j1; j++) {
-          uint32_t d = digits[(size_t)w * n + j];
-          if (d != DIGIT_NONE) entries[(size_t)w * n + off[d >> 1]++] = j | ((d & 1u) << 31);
-        }
-      }
+      bs[B] = run;
+      std::vector<uint32_t> cur(bs, bs + B);
+      for (uint32_t j = 0; j < n; j++)
+        if (dg[j] != DIGIT_NONE) a.entries[(size_t)w * n + cur[dg[j] >> 1]++] = j | ((dg[j] & 1u) << 31);
     }
   }
   template <class F>

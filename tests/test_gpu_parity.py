@@ -290,7 +290,7 @@ def test_window_sizes_and_lane_spans(dev, torch_cuda):
     expect = bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
     dp, ds = _to_dev(torch, pts), _to_dev(torch, sc)
     try:
-        for c, K, S in ((3, 4, 0), (5, 8, 1), (8, 16, 3), (13, 0, 0), (15, 12, 2), (16, 0, 0), (0, 0, 0)):
+        for c, K, S in ((3, 4, 0), (5, 8, 64), (8, 16, 1000), (13, 0, 0), (15, 12, 3000), (16, 0, 0), (0, 0, 0)):
             dev.set_option("c", c)
             dev.set_option("K", K)
             dev.set_option("S", S)
@@ -299,6 +299,38 @@ def test_window_sizes_and_lane_spans(dev, torch_cuda):
         dev.set_option("c", 0)
         dev.set_option("K", 0)
         dev.set_option("S", 0)
+
+
+def test_sort_under_skewed_digit_distributions(dev, torch_cuda):
+    """The two-pass bucket sort (partition by bucket group, LDS sort per group) must not depend on the digits being
+    uniform: giant buckets (bypass the LDS image), groups several tiles long, medium buckets straddling a tile end."""
+    torch = torch_cuda
+    name = "bn254_snarks_g1"
+    n = 1 << 18
+    pts = cref.gen_points(name, 311, n)
+    dp = _to_dev(torch, pts)
+    rng = np.random.default_rng(7)
+    uni = cref.synth_scalars(312, n, 254)
+    cases = {"uniform": uni}
+    few = uni[:5]
+    cases["five distinct scalars"] = few[rng.integers(0, 5, n)]
+    some = uni[:100]
+    cases["hundred distinct scalars"] = some[rng.integers(0, 100, n)]
+    low = uni.copy()
+    low[:, 1::2] &= 0x1F          # every 16-bit chunk < 2^13: three quarters of the bucket range stay empty
+    cases["low quarter of the bucket range"] = low
+    mix = uni.copy()
+    mix[: n // 2] = some[rng.integers(0, 100, n // 2)]
+    cases["half uniform, half repeated"] = mix
+    try:
+        for label, sc in cases.items():
+            sc = np.ascontiguousarray(sc)
+            expect = bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
+            for c in ((0, 11, 12, 13, 14, 15) if label == "uniform" else (0, 12)):   # 11..14: short top windows
+                dev.set_option("c", c)
+                assert bytes(dev.msm(name, _to_dev(torch, sc), dp, n, coord="aff")) == expect, (label, c)
+    finally:
+        dev.set_option("c", 0)
 
 
 # ----------------------------------------------------------------------------------------------

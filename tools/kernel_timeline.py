@@ -12,9 +12,9 @@ def main(path, as_markdown=False):
     rows = list(cur.execute(
         "select s.kernel_name, d.start, d.end, d.grid_size_x, d.grid_size_y, d.workgroup_size_x "
         "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start"))
-    idx = [i for i, r in enumerate(rows) if "k_digits" in r[0]]
+    idx = [i for i, r in enumerate(rows) if "k_digits" in r[0]] or [i for i, r in enumerate(rows) if "k_part_count" in r[0] and (i == 0 or "k_part_count" not in rows[i - 1][0])]
     if not idx:
-        print("no k_digits dispatch found")
+        print("no MSM dispatch found")
         return
     last = rows[idx[-1]:]
     t0 = last[0][1]
