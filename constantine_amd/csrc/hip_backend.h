@@ -67,6 +67,118 @@ template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_batch_affine(BatchAffineArgs<F> a) {
   batch_affine_body<F>(a, blockIdx.x * blockDim.x + threadIdx.x);
 }
+// --- four lanes per addition -------------------------------------------------------------------------------------
+// The late passes of the bucket reduction (and the head-merge steps) have only a few hundred additions per window
+// left: one lane per addition leaves the chip idle while every lane walks 14 dependent field products (~18 us).
+// Here a quad of lanes shares one addition: the 14 products of the XYZZ sum are arranged in 4 rounds of (up to) 4
+// independent products, one per lane, with quad broadcasts in between -- 4 products deep instead of 14.
+//   round 1   U1 = X1*ZZ2      U2 = X2*ZZ1      S1 = Y1*ZZZ2      S2 = Y2*ZZZ1
+//   round 2   PP = P^2         RR = R^2         Z2 = ZZ1*ZZ2      Z3 = ZZZ1*ZZZ2        (P = U2-U1, R = S2-S1)
+//   round 3   PPP = P*PP       Q = U1*PP        ZZ3 = Z2*PP       -
+//   round 4   A = R*(Q-X3)     Bv = S1*PPP      -                 ZZZ3 = Z3*PPP         (X3 = RR-PPP-2Q, Y3 = A-Bv)
+// Exceptional inputs (a neutral operand, P = +-Q) are rare here: lane 0 of the quad then runs the ordinary addition.
+template <class F>
+__device__ __forceinline__ F quad_bcast(const F& v, int src_role) {
+  const int src = (int)((threadIdx.x & ~3u) | (uint32_t)src_role) & 63;
+  F r;
+  if constexpr (IsFp2<F>::value) {
+    r.c0 = quad_bcast(v.c0, src_role);
+    r.c1 = quad_bcast(v.c1, src_role);
+  } else {
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(F) / 4); i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], src, 64);
+  }
+  return r;
+}
+
+template <class F>
+__device__ __forceinline__ void xyzz_add_quad(const XYZZ<F>* s1, const XYZZ<F>* s2, XYZZ<F>* d1, XYZZ<F>* d2, int role) {
+  constexpr int M = F::MULB;
+  const F* A = &s1->x;  // x, y, zz, zzz
+  const F* Q = &s2->x;
+  const bool ainf = A[2].is_zero(), qinf = Q[2].is_zero();
+  bool plain = ainf | qinf;
+  F U1, U2, S1, S2, P, R;
+  if (!plain) {
+    const int hi = role >> 1;
+    const bool fromq = (role & 1) != 0;
+    const F opA = fromq ? Q[hi] : A[hi];          // a.x | q.x | a.y | q.y
+    const F opB = fromq ? A[2 + hi] : Q[2 + hi];  // q.zz | a.zz | q.zzz | a.zzz
+    const F T1 = F::mul(opA, opB);
+    U1 = quad_bcast<F>(T1, 0);
+    U2 = quad_bcast<F>(T1, 1);
+    S1 = quad_bcast<F>(T1, 2);
+    S2 = quad_bcast<F>(T1, 3);
+    P = fsub<F, M>(U2, U1);  // < 2M
+    R = fsub<F, M>(S2, S1);  // < 2M
+    plain = fis_zero_modp<F, 2 * M>(P);
+  }
+  if (plain) {  // uniform inside the quad
+    if (role == 0) {
+      const XYZZ<F> x = *s1, y = *s2;
+      const XYZZ<F> r = xyzz_add_inl<F>(x, y);
+      *d1 = r;
+      if (d2) *d2 = r;
+    }
+    return;
+  }
+  const int zi = role >= 2 ? role : 2;
+  const F za = A[zi], zq = Q[zi];
+  const F PR = F::select(role == 0, P, R);
+  const F T2 = F::mul(F::select(role < 2, PR, za), F::select(role < 2, PR, zq));  // PP | RR | Z2 | Z3
+  const F PP = quad_bcast<F>(T2, 0);
+  const F RR = quad_bcast<F>(T2, 1);
+  const F T3 = F::mul(F::select(role == 0, P, F::select(role == 1, U1, T2)), PP);  // PPP | Q | ZZ3 | (unused)
+  const F PPP = quad_bcast<F>(T3, 0);
+  const F Qv = quad_bcast<F>(T3, 1);
+  const F X3 = fsub<F, 2 * M>(fsub<F, M>(RR, PPP), F::dbl(Qv));  // < 4M
+  const F T4 = F::mul(F::select(role == 0, R, F::select(role == 1, S1, T2)),
+                      F::select(role == 0, fsub<F, 4 * M>(Qv, X3), PPP));        // A | Bv | (unused) | ZZZ3
+  const F Bv = quad_bcast<F>(T4, 1);
+  if (role == 0) {
+    const F Y3 = fsub<F, M>(T4, Bv);  // < 2M
+    d1->x = X3;
+    d1->y = Y3;
+    if (d2) { d2->x = X3; d2->y = Y3; }
+  } else if (role == 2) {
+    d1->zz = T3;
+    if (d2) d2->zz = T3;
+  } else if (role == 3) {
+    d1->zzz = T4;
+    if (d2) d2->zzz = T4;
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_pyr_quad(PyrArgs<F> a, uint32_t ntasks) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = lane >> 2;
+  const int role = (int)(lane & 3u);
+  const XYZZ<F>* s1;
+  const XYZZ<F>* s2;
+  XYZZ<F>* d1;
+  XYZZ<F>* d2;
+  const bool live = t < ntasks && pyr_decode<F>(a, blockIdx.y, t, s1, s2, d1, d2);
+  if (!live) return;  // whole quads leave together (t is the same for the four lanes)
+  if (!s2) {
+    if (role == 0) {
+      const XYZZ<F> x = *s1;
+      *d1 = x;
+      if (d2) *d2 = x;
+    }
+    return;
+  }
+  xyzz_add_quad<F>(s1, s2, d1, d2, role);
+}
+// head-merge tree step with four lanes per addition (a step has at most G / 2d additions per window)
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_step_quad(MergeArgs<F> a, uint32_t d) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = lane >> 2;
+  if (!merge_step_active<F>(a, blockIdx.y, g, d)) return;
+  XYZZ<F>* h = a.heads + (uint64_t)blockIdx.y * a.G + g;
+  xyzz_add_quad<F>(h, h + d, h, (XYZZ<F>*)nullptr, (int)(lane & 3u));
+}
 template <class C>
 __global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t first, uint32_t n, Affine<typename C::F>* out) {
   Affine<typename C::F> G = generator<C>();
@@ -215,6 +327,11 @@ struct HipBackend {
   }
   template <class F>
   void launch_merge_step(const MergeArgs<F>& a, uint32_t W, uint32_t d) {
+    if ((uint64_t)a.G * W * 4u <= 1048576u) {  // the additions of a step are sparse: four lanes each
+      hipLaunchKernelGGL(k_merge_step_quad<F>, grid2(a.G * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, d);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     hipLaunchKernelGGL(k_merge_step<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, d);
     HIP_CHECK(hipGetLastError());
   }
@@ -225,6 +342,13 @@ struct HipBackend {
   }
   template <class F>
   void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
+    // few tasks left: four lanes per addition (the chip is mostly idle, the addition is 3.5x shallower)
+    static const uint32_t quad_env = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 32768u;
+    if ((uint64_t)ntasks * W <= quad_env) {
+      hipLaunchKernelGGL(k_pyr_quad<F>, grid2(ntasks * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, ntasks);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     hipLaunchKernelGGL(k_pyr<F>, grid2(ntasks, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, ntasks);
     HIP_CHECK(hipGetLastError());
   }

@@ -236,20 +236,26 @@ CTT_HD void merge_tail_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
 }
 
 // tree step over the chain of heads of one bucket: heads[g] += heads[g+d] for g-chain_start = 0 mod 2d
+// (true when lane g has an addition to do in this step)
 template <class F>
-CTT_HD void merge_step_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint32_t d) {
-  if (g >= a.G) return;
+CTT_HD bool merge_step_active(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint32_t d) {
+  if (g >= a.G) return false;
   // longest possible chain is floor((maxcount-1)/K)+1 heads
   const uint32_t mc = *a.maxcount;
-  if (mc == 0 || d >= (mc - 1) / a.K + 1) return;
+  if (mc == 0 || d >= (mc - 1) / a.K + 1) return false;
   const uint64_t slot = (uint64_t)w * a.G + g;
   const uint32_t b = a.hkey[slot];
-  if (b == KEY_NONE) return;
+  if (b == KEY_NONE) return false;
   const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
   const uint32_t s = bs[b] / a.K + 1;
   const uint32_t e = (bs[b + 1] - 1) / a.K;
   const uint32_t rel = g - s;
-  if ((rel % (2 * d)) != 0 || g + d > e) return;
+  return (rel % (2 * d)) == 0 && g + d <= e;
+}
+template <class F>
+CTT_HD void merge_step_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint32_t d) {
+  if (!merge_step_active<F>(a, w, g, d)) return;
+  const uint64_t slot = (uint64_t)w * a.G + g;
   XYZZ<F> x = a.heads[slot];
   XYZZ<F> y = a.heads[slot + d];
   a.heads[slot] = xyzz_add_inl<F>(x, y);
@@ -313,17 +319,18 @@ CTT_HD uint32_t pyr_pass_tasks(uint32_t B, int c, int p) {
   return n;
 }
 
+// Task t of pass a.p in window w: *d1 (and *d2 when set) = *s1 + *s2 (a plain copy when s2 is null).
+// Returns false when t is not a task of this pass.
 template <class F>
-CTT_HD void pyr_body(const PyrArgs<F>& a, uint32_t w, uint32_t t) {
+CTT_HD bool pyr_decode(const PyrArgs<F>& a, uint32_t w, uint32_t t, const XYZZ<F>*& s1, const XYZZ<F>*& s2, XYZZ<F>*& d1,
+                       XYZZ<F>*& d2) {
   const uint32_t B = a.B;
   const int c = a.c, p = a.p;
   XYZZ<F>* out = a.out + (uint64_t)w * c;
-  // Decode the task into (src1, src2, dst, dst2) first and run ONE addition afterwards, so that the
-  // lanes of a wave that hold different task kinds still execute the (expensive) addition together.
-  const XYZZ<F>* s1 = nullptr;
-  const XYZZ<F>* s2 = nullptr;
-  XYZZ<F>* d1 = nullptr;
-  XYZZ<F>* d2 = nullptr;
+  s1 = nullptr;
+  s2 = nullptr;
+  d1 = nullptr;
+  d2 = nullptr;
   const uint32_t na = B >> (p + 1);                 // (a) pyramid: level p+1 from level p
   const uint32_t L = B >> (p + 1);                  // (b) odd elements of level p
   const uint32_t nb = (L >= 2) ? L / 2 : 1;
@@ -364,7 +371,18 @@ CTT_HD void pyr_body(const PyrArgs<F>& a, uint32_t w, uint32_t t) {
       u -= nc;
     }
   }
-  if (!s1) return;
+  return s1 != nullptr;
+}
+
+template <class F>
+CTT_HD void pyr_body(const PyrArgs<F>& a, uint32_t w, uint32_t t) {
+  // Decode the task into (src1, src2, dst, dst2) first and run ONE addition afterwards, so that the
+  // lanes of a wave that hold different task kinds still execute the (expensive) addition together.
+  const XYZZ<F>* s1;
+  const XYZZ<F>* s2;
+  XYZZ<F>* d1;
+  XYZZ<F>* d2;
+  if (!pyr_decode<F>(a, w, t, s1, s2, d1, d2)) return;
   XYZZ<F> x = *s1;
   if (s2) {
     XYZZ<F> y = *s2;
