@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert len([s for s in declared if s.endswith('_batch_affine') and 'hip' not in s]) == 12
-    assert L.ctt_hip_msm_abi_version() == 2
+    assert L.ctt_hip_msm_abi_version() == _lib.ABI_VERSION
 
 
 def test_host_only_point_sum_matches_oracle():

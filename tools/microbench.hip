@@ -39,6 +39,24 @@ DEF_KERNEL(k_mac,
   _Pragma("unroll") for (int i = 0; i < UNROLL; i++) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(a[i]), "+v"(h[i]) : "v"(x), "v"(y) : "vcc"),
   (uint32_t)(a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5] ^ a[6] ^ a[7]) ^ h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4] ^ h[5] ^ h[6] ^ h[7])
 
+// --- co-issue probes: does another pipe run underneath the 64-bit integer multiplier? -------------------------
+// 8 independent v_mad_u64_u32 chains interleaved 1:1 with 8 independent chains of a second instruction
+DEF_KERNEL(k_mad64_plus_fma64,
+  uint64_t a[UNROLL]; double f[UNROLL]; uint32_t x = tid * 2654435761u + seed; uint32_t y = x ^ 0x9e3779b9u; double g = 1.0 + x * 1e-9;
+  for (int i = 0; i < UNROLL; i++) { a[i] = x + i; f[i] = g + i; },
+  _Pragma("unroll") for (int i = 0; i < UNROLL; i++) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_fma_f64 %1, %1, %4, %1" : "+v"(a[i]), "+v"(f[i]) : "v"(x), "v"(y), "v"(g) : "vcc"),
+  (uint32_t)(a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5] ^ a[6] ^ a[7]) ^ (uint32_t)(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]))
+DEF_KERNEL(k_mad64_plus_add32,
+  uint64_t a[UNROLL]; uint32_t b[UNROLL]; uint32_t x = tid * 2654435761u + seed; uint32_t y = x ^ 0x9e3779b9u;
+  for (int i = 0; i < UNROLL; i++) { a[i] = x + i; b[i] = i; },
+  _Pragma("unroll") for (int i = 0; i < UNROLL; i++) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_add_u32 %1, %1, %2" : "+v"(a[i]), "+v"(b[i]) : "v"(x), "v"(y) : "vcc"),
+  (uint32_t)(a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5] ^ a[6] ^ a[7]) ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ b[4] ^ b[5] ^ b[6] ^ b[7])
+DEF_KERNEL(k_mad64_plus_mad24,
+  uint64_t a[UNROLL]; uint32_t b[UNROLL]; uint32_t x = tid * 2654435761u + seed; uint32_t y = x ^ 0x9e3779b9u;
+  for (int i = 0; i < UNROLL; i++) { a[i] = x + i; b[i] = i; },
+  _Pragma("unroll") for (int i = 0; i < UNROLL; i++) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u32_u24 %1, %1, %2, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(x), "v"(y) : "vcc"),
+  (uint32_t)(a[0] ^ a[1] ^ a[2] ^ a[3] ^ a[4] ^ a[5] ^ a[6] ^ a[7]) ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ b[4] ^ b[5] ^ b[6] ^ b[7])
+
 #define DEF32(NAME, ASM)                                                                \
   DEF_KERNEL(NAME,                                                                      \
     uint32_t a[UNROLL]; uint32_t x = tid * 2654435761u + seed;                          \
@@ -132,6 +150,9 @@ int main(int argc, char** argv) {
   }
   RUN("v_mad_u64_u32", k_mad64, 1)
   RUN("mac(v_mad_u64_u32+v_addc_co_u32)", k_mac, 1)
+  RUN("pair(v_mad_u64_u32 + v_fma_f64), pairs/s", k_mad64_plus_fma64, 1)
+  RUN("pair(v_mad_u64_u32 + v_add_u32), pairs/s", k_mad64_plus_add32, 1)
+  RUN("pair(v_mad_u64_u32 + v_mad_u32_u24), pairs/s", k_mad64_plus_mad24, 1)
   RUN("v_mul_lo_u32", k_mul_lo, 1)
   RUN("v_mul_hi_u32", k_mul_hi, 1)
   RUN("v_add_u32", k_add_u32, 1)
