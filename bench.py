@@ -27,6 +27,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+# v_mad_u64_u32 per mixed addition of the accumulate kernel: 8 products + 2 squares + 9 Montgomery reductions on NL
+# carry-free limbs = 8 NL^2 + NL (NL + 1) + 9 NL^2 (NL = 14 for BLS12-381, 9 for the 254/255-bit fields); DESIGN.md 4.3
+MADS_PER_MIXED_ADD = {"bls12_381_g1": 3542, "bn254_snarks_g1": 1467, "pallas": 1467, "vesta": 1467}
+INT_MAD_PEAK = 31.0e12         # v_mad_u64_u32 lane-ops/s, measured on MI355X (profiles/microbench_fpu_r01.jsonl: 79.2 G products/s x 393)
 BYTES_PER_PAIR = {"bls12_381_g1": 128, "bn254_snarks_g1": 96, "pallas": 96, "vesta": 96, "bls12_381_g2": 224}
 
 
@@ -182,8 +186,14 @@ def main():
             "bound": "hbm", "kernel": "k_accum", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": stages.get("accumulate", 0.0), "algorithmic_bytes": alg_bytes,
-            "note": "integer-VALU bound by construction (no dense contraction); see DESIGN.md for the int-MAD roof",
+            "note": "integer-VALU bound by construction (no dense contraction); the binding roof is `int_mad` below",
         }
+        if curve in MADS_PER_MIXED_ADD and t_acc > 0:
+            mads = plan["W"] * n * MADS_PER_MIXED_ADD[curve]      # one mixed addition per (window, pair)
+            out["roofline"]["int_mad"] = {
+                "instr": "v_mad_u64_u32", "per_launch": mads, "achieved": mads / t_acc / 1e12, "peak": INT_MAD_PEAK / 1e12,
+                "unit": "T lane-ops/s", "frac": mads / t_acc / INT_MAD_PEAK,
+            }
         # ---- CPU baseline: the oracle port on the host cores, bounded sample; doubles as a parity check -----
         if world == 1 and not args.no_cpu_baseline:
             m = min(n, 1 << args.cpu_sample_log2)

@@ -343,7 +343,7 @@ struct HipBackend {
   template <class F>
   void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
     // few tasks left: four lanes per addition (the chip is mostly idle, the addition is 3.5x shallower)
-    static const uint32_t quad_env = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 32768u;
+    static const uint32_t quad_env = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 24576u;  // measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768
     if ((uint64_t)ntasks * W <= quad_env) {
       hipLaunchKernelGGL(k_pyr_quad<F>, grid2(ntasks * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, ntasks);
       HIP_CHECK(hipGetLastError());

@@ -36,5 +36,7 @@ timeout 300 python bench.py --curve bls12_381_g2 --steps 10 --warmup 2 --no-cpu-
 for k in 16 18 22 24; do
   timeout 300 python bench.py --log2n $k --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g1_2pow$k.json" 2>> "$OUT/bench.err"
 done
+timeout 300 python tools/bench_batch_ops.py > "$OUT/batch_ops_$TAG.txt" 2>> "$OUT/bench.err"
+timeout 300 python tools/bench_hostptr.py > "$OUT/hostptr_$TAG.txt" 2>> "$OUT/bench.err"
 find "$OUT/prof" -name "*.db" -delete 2>/dev/null   # the rocpd databases are large; the summaries are what is kept
 tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench_$TAG.json"

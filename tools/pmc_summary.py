@@ -4,8 +4,8 @@
     python tools/pmc_summary.py <fetch_dir> <write_dir> <key> <out.json> <out.txt>
 
 gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts every 128-B request as 64 B, so
-read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is.  k_digits is the in-run calibration: it reads
-N x 32 B of scalars and writes W x N x 4 B of digits, both known exactly.
+read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is.  In-run calibration: k_part_count reads exactly
+N x 32 B of scalars, k_group_sort writes W x N x 4 B of entries (+ the bucket_start array).
 """
 import csv
 import glob
@@ -44,7 +44,8 @@ def main():
         for k, n, f, w in rows:
             o.write(f"{k}, {n}, {f:.1f}, {w:.1f}, {int(2 * f * 1024 + w * 1024)}\n")
     acc = next((r for r in rows if "k_accum" in r[0]), None)
-    dig = next((r for r in rows if r[0].endswith("k_digits")), None)
+    cal_r = next((r for r in rows if r[0].endswith("k_part_count")), None)
+    cal_w = next((r for r in rows if r[0].endswith("k_group_sort")), None)
     doc = {}
     if os.path.exists(out_json):
         try:
@@ -55,11 +56,12 @@ def main():
         doc[key] = int(2 * acc[2] * 1024 + acc[3] * 1024)
         doc.setdefault("_detail", {})[key] = {
             "kernel": acc[0], "launches_averaged": acc[1], "FETCH_SIZE_KiB_raw": acc[2], "WRITE_SIZE_KiB_raw": acc[3],
-            "calibration_k_digits": None if not dig else {"FETCH_SIZE_KiB_raw": dig[2], "WRITE_SIZE_KiB_raw": dig[3]},
+            "calibration": {"k_part_count_FETCH_SIZE_KiB_raw": cal_r[2] if cal_r else None,
+                            "k_group_sort_WRITE_SIZE_KiB_raw": cal_w[3] if cal_w else None},
         }
         doc["_correction"] = ("gfx950 rocprofv3 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section): "
-                              "fetch bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is. k_digits (reads N x 32 B, "
-                              "writes W x N x 4 B) is the in-run calibration.")
+                              "fetch bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is. In-run calibration: k_part_count reads "
+                              "N x 32 B (2^20 pairs: 33.55 MB), k_group_sort writes W x N x 4 B + bucket_start (69.2 MB).")
         doc["_commands"] = [
             "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
             "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
