@@ -89,6 +89,7 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   static const uint32_t slenv = getenv("CTT_SORT_SLICE") ? (uint32_t)atoi(getenv("CTT_SORT_SLICE")) : 2048u;
   uint32_t slice = o.S > 0 ? (uint32_t)o.S : slenv;
   while (o.S <= 0 && (uint64_t)slice * 512u < n) slice <<= 1;
+  while (o.S <= 0 && slice > 64u && (uint64_t)slice * 64u > n) slice >>= 1;  // small n: at least ~64 partition blocks
   p.slice = slice;
   p.S = (n + slice - 1) / slice;
   p.jbits = 1;
