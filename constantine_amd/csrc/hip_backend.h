@@ -44,8 +44,8 @@ __global__ void __launch_bounds__(ACCUM_BLOCK, (sizeof(XYZZ<F>) > 256 ? 1 : CTT_
   accum_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
 }
 template <class F>
-__global__ void __launch_bounds__(EC_BLOCK) k_merge_tail(MergeArgs<F> a) {
-  merge_tail_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_tail(MergeArgs<F> a, bool final_) {
+  merge_tail_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, final_);
 }
 template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_merge_step(MergeArgs<F> a, uint32_t d) {
@@ -321,8 +321,8 @@ struct HipBackend {
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
-  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W) {
-    hipLaunchKernelGGL(k_merge_tail<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
+  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W, bool final_) {
+    hipLaunchKernelGGL(k_merge_tail<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, final_);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>

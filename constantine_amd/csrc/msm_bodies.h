@@ -225,14 +225,17 @@ struct MergeArgs {
 };
 
 // heads[g+1] += tails[g]: a tail is the first piece of a straddling bucket, the next lane's head continues it
+// `final_` (no bucket spans more than two lanes, i.e. every chain of heads has length one): the sum is the bucket.
 template <class F>
-CTT_HD void merge_tail_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
+CTT_HD void merge_tail_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, bool final_) {
   if (g + 1 >= a.G) return;
   const uint64_t slot = (uint64_t)w * a.G + g;
-  if (a.tkey[slot] == KEY_NONE) return;
+  const uint32_t b = a.tkey[slot];
+  if (b == KEY_NONE) return;
   XYZZ<F> h = a.heads[slot + 1];
   XYZZ<F> t = a.tails[slot];
-  a.heads[slot + 1] = xyzz_add_inl<F>(h, t);
+  XYZZ<F> r = xyzz_add_inl<F>(h, t);
+  if (final_) a.buckets[(uint64_t)w * a.B + b] = r; else a.heads[slot + 1] = r;
 }
 
 // tree step over the chain of heads of one bucket: heads[g] += heads[g+d] for g-chain_start = 0 mod 2d

@@ -283,12 +283,16 @@ struct MsmEngine {
 
     bk.stage_begin(sl, ST_MERGE);
     MergeArgs<FD> ma{d_bstart, d_buckets, d_heads, d_tails, d_hkey, d_tkey, d_maxcount, B, p.K, p.G};
-    bk.template launch_merge_tail<FD>(ma, W);
     // tree steps over the head chain of a bucket: a bucket of m entries spans at most floor((m-1)/K)+1 heads
+    // (the largest bucket was read back while the accumulation ran).  With chains of length one -- the common case,
+    // no bucket larger than K -- the tail merge writes the buckets itself.
     const uint32_t mc = bk.fetch_u32_wait();
     const uint32_t chain = mc ? (mc - 1) / p.K + 1 : 0;
-    for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<FD>(ma, W, d);
-    bk.template launch_merge_final<FD>(ma, W);
+    bk.template launch_merge_tail<FD>(ma, W, chain <= 1);
+    if (chain > 1) {
+      for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<FD>(ma, W, d);
+      bk.template launch_merge_final<FD>(ma, W);
+    }
     bk.stage_end(sl, ST_MERGE);
 
     bk.stage_begin(sl, ST_REDUCE);
@@ -370,7 +374,7 @@ struct MsmEngine {
     AccumArgs<FD> aa{d_entries, d_bstart, d_points, point_stride, d_buckets, d_heads, d_tails, d_hkey, d_tkey, n, 1, K, G};
     bk.template launch_accum<FD>(aa, 1);
     MergeArgs<FD> ma{d_bstart, d_buckets, d_heads, d_tails, d_hkey, d_tkey, d_maxcount, 1, K, G};
-    bk.template launch_merge_tail<FD>(ma, 1);
+    bk.template launch_merge_tail<FD>(ma, 1, false);
     for (uint32_t d = 1; d < G; d <<= 1) bk.template launch_merge_step<FD>(ma, 1, d);
     bk.template launch_merge_final<FD>(ma, 1);
     XYZZ<FD> raw;

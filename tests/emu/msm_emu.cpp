@@ -69,8 +69,8 @@ struct EmuBackend {
     for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) accum_body<F>(a, w, g);
   }
   template <class F>
-  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W) {
-    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_tail_body<F>(a, w, g);
+  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W, bool final_) {
+    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_tail_body<F>(a, w, g, final_);
   }
   template <class F>
   void launch_merge_step(const MergeArgs<F>& a, uint32_t W, uint32_t d) {
