@@ -142,7 +142,8 @@ int ctt_hip_msm_abi_version(void);
  * context on device $CTT_HIP_DEVICE (default 0). */
 ctt_hip_msm_ctx* ctt_hip_msm_ctx_create(int device);
 void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
-/* key in {"c","K","S","lanes"}; value 0 = automatic ("lanes": 1 or 2 streams for submit). Returns 0, or -1 for an unknown key. */
+/* key in {"c","K","S","lanes"}: window bits, sorted entries per accumulate lane, scalars per sort-partition workgroup;
+ * value 0 = automatic ("lanes": 1 or 2 streams for submit). Returns 0, or -1 for an unknown key. */
 int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
 /* r (HOST memory, `out_kind` layout) = sum coefs[i] * points[i]; d_coefs / d_points are DEVICE pointers
  * (BigInt canonical or Fr Montgomery 32-byte scalars; affine Montgomery points, C-API struct layout).

@@ -301,6 +301,17 @@ def test_window_sizes_and_lane_spans(dev, torch_cuda):
         dev.set_option("S", 0)
 
 
+@pytest.mark.parametrize("n", [16385, 40000, 100003, (1 << 20) + 7])
+def test_sizes_around_the_sort_group_boundaries(dev, torch_cuda, n):
+    """Pair counts that are not powers of two (ragged last partition block, groups of uneven size)."""
+    torch = torch_cuda
+    name = "pallas"
+    pts = cref.gen_points(name, 411, n)
+    sc = cref.synth_scalars(412, n, 255)
+    expect = bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
+    assert bytes(dev.msm(name, _to_dev(torch, sc), _to_dev(torch, pts), n, coord="aff")) == expect
+
+
 def test_sort_under_skewed_digit_distributions(dev, torch_cuda):
     """The two-pass bucket sort (partition by bucket group, LDS sort per group) must not depend on the digits being
     uniform: giant buckets (bypass the LDS image), groups several tiles long, medium buckets straddling a tile end."""
