@@ -23,6 +23,7 @@ namespace ctt {
 
 template <class UP>
 struct FpU {
+  static constexpr int HEADROOM_LOG2 = UP::RP_OVER_P_LOG2;  // log2(R'/p): a product of operands < k1*p, k2*p needs k1*k2 < R'/p
   using Params = UP;
   using Sat = Fp<typename UP::Sat>;
   static constexpr int NL = UP::NL;
@@ -387,6 +388,7 @@ struct Fp2<FpU<UP>> {
   static constexpr int MULB = 2;
   static constexpr bool UNSAT = true;
   static constexpr int KNEG = 10;
+  static constexpr int HEADROOM_LOG2 = UP::RP_OVER_P_LOG2;  // log2(R'/p): operand bounds k1*k2 must stay below it
   static constexpr int LB = F::LB;
   static constexpr int NL = 2 * F::NL;   // limbs of the whole element (c0 then c1)
   static_assert(2 * KNEG * KNEG < (1 << UP::RP_OVER_P_LOG2), "Fp2 over this base field needs more Montgomery headroom");
@@ -412,6 +414,9 @@ struct Fp2<FpU<UP>> {
   CTT_HD static Fp2 cneg(const Fp2& a, bool c) {
     return {F::template cneg<B>(a.c0, c), F::template cneg<B>(a.c1, c)};
   }
+  // Karatsuba on unreduced columns (3 limb products, 2 reductions) was tried: the six live operands plus two sets
+  // of Montgomery quotients spill the accumulate kernel to scratch (G2 accumulate 8.7 -> 126 ms); two sums of
+  // products it is.
   CTT_HD static Fp2 mul(const Fp2& a, const Fp2& b) {
     F na1 = F::template sub<KNEG>(F::zero(), a.c1);
     return {F::mul2(a.c0, b.c0, na1, b.c1), F::mul2(a.c0, b.c1, a.c1, b.c0)};
@@ -419,7 +424,7 @@ struct Fp2<FpU<UP>> {
   CTT_HD static Fp2 sqr(const Fp2& a) {
     F s = F::add(a.c0, a.c1);
     F d = F::template sub<KNEG>(a.c0, a.c1);
-    return {F::mul(s, d), F::mul2(a.c0, a.c1, a.c0, a.c1)};
+    return {F::mul(s, d), F::mul(F::dbl(a.c0), a.c1)};   // (a0+a1)(a0-a1), 2 a0 a1: two products, two reductions
   }
   // a*b + c*d: two products (not fused further: four base sum-of-products)
   CTT_HD static Fp2 mul2(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return add(mul(a, b), mul(c, d)); }

@@ -198,6 +198,17 @@ __global__ void k_field_op_dev(int op, const F* a, const F* b, FD* r, uint32_t n
       case 1: o = FD::sqr(x); break;
       case 2: o = FD::add(x, y); break;
       case 3: o = FD::template sub<2>(x, y); break;
+      // operands at the largest bounds the curve arithmetic feeds into a product (ec.h: 5M and 3M, M = 2)
+      case 5: {
+        constexpr int BA = FD::HEADROOM_LOG2 >= 7 ? 9 : 5, BB = FD::HEADROOM_LOG2 >= 7 ? 9 : 4;
+        o = FD::mul(FD::template sub<BA>(x, FD::zero()), FD::template sub<BB>(y, FD::zero()));
+        break;
+      }
+      case 6: {
+        constexpr int BA = FD::HEADROOM_LOG2 >= 7 ? 9 : 5;
+        o = FD::sqr(FD::template sub<BA>(x, FD::zero()));
+        break;
+      }
       default: o = x; break;
     }
     r[j] = o;

@@ -111,7 +111,8 @@ def test_carry_free_field_on_device(name, dev, torch_cuda):
     b = np.frombuffer(b"".join(F.to_mont_bytes(x) for x in B), dtype=np.uint8).reshape(n, -1).copy()
     da, db = _to_dev(torch, a), _to_dev(torch, b)
     dr = torch.zeros((n, nl * deg), dtype=torch.int32, device="cuda")
-    ops = {0: (F.mul, 2), 1: (lambda x, y: F.sqr(x), 2), 2: (F.add, 4), 3: (F.sub, 4), 4: (lambda x, y: x, 2)}
+    ops = {0: (F.mul, 2), 1: (lambda x, y: F.sqr(x), 2), 2: (F.add, 4), 3: (F.sub, 4), 4: (lambda x, y: x, 2),
+           5: (F.mul, 2), 6: (lambda x, y: F.sqr(x), 2)}   # 5, 6: operands biased up to the largest bounds ec.h feeds into a product
     for op, (fn, bound) in ops.items():
         dev.field_op(name, 16 + op, da, db, dr, n)
         out = dr.cpu().numpy().astype(np.uint32)
