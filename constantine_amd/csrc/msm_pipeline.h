@@ -82,6 +82,13 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   p.c = o.c > 0 ? o.c : choose_window_bits(n, bits, o.lanes);
   if (p.c < 2) p.c = 2;
   if (p.c > 16) p.c = 16;
+  {
+    // the sort packs (low bucket bits | sign | point index) into 32 bits with at most 4096 bucket groups per window:
+    // beyond 2^28 pairs that caps the window width (c <= 44 - bits(n): 15 at 2^29, 13 at 2^31)
+    uint32_t jb = 1;
+    while (jb < 31 && (1ull << jb) < n) jb++;
+    while (p.c > 2 && (int)jb + 1 + (p.c - 1 - 12) > 32) p.c--;
+  }
   p.W = bits / p.c + 1;  // ec_multi_scalar_mul_parallel.nim:157-158: one more window when c | bits
   p.B = 1u << (p.c - 1);
   // sort pass A: ~512 partition blocks of at least 2048 scalars; pass B: groups of ~16384 entries (one workgroup
@@ -102,7 +109,7 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   p.cap = capenv;
   p.big = bigenv;
   uint32_t NG = 1;
-  while ((uint64_t)NG * gsz < n) NG <<= 1;
+  while ((uint64_t)NG * gsz < n && NG < 4096u) NG <<= 1;  // beyond 2^26 pairs the groups grow instead (tiled in pass B)
   while (NG < p.B && p.B / NG > 1024u) NG <<= 1;
   if (NG > p.B) NG = p.B;
   p.gshift = 0;
