@@ -4,8 +4,8 @@
 // (constantine/math/elliptic/ec_multi_scalar_mul.nim:204-296, ..._parallel.nim:148-431) with a
 // sort-then-segmented-reduce pipeline:
 //
-//   digits   Booth signed window digits of every scalar     (bigints.nim:806-859)
-//   hist/scan/scatter   counting sort of (point index, sign) by bucket, per window  [LDS kernels]
+//   sort     Booth signed window digits of every scalar (bigints.nim:806-859), then (point index, sign) entries
+//            grouped by bucket per window: partition by bucket group + LDS sort per group  [kernels in msm_engine.hip]
 //   accum    every lane sums K consecutive sorted entries into XYZZ accumulators
 //            (mixed add = the reference's `accumulate`, ec_multi_scalar_mul.nim:177-184);
 //            runs fully inside a lane's range go straight to the bucket array, runs that
@@ -63,18 +63,6 @@ CTT_HD uint32_t booth_digit_packed(const uint32_t* k, int w, int c) {
   uint32_t val = neg ? (1u << c) - e : e;
   val &= (1u << c) - 1u;
   return val ? (((val - 1u) << 1) | neg) : DIGIT_NONE;
-}
-
-struct DigitsArgs {
-  const uint32_t* scalars;  // [N][8] canonical
-  uint32_t* digits;         // [W][N]
-  uint32_t N;
-  int c, W;
-};
-CTT_HD void digits_body(const DigitsArgs& a, uint32_t j) {
-  if (j >= a.N) return;
-  const uint32_t* k = a.scalars + 8ull * j;
-  for (int w = 0; w < a.W; w++) a.digits[(uint64_t)w * a.N + j] = booth_digit_packed(k, w, a.c);
 }
 
 // Digits + sort by bucket.  Output contract (what the accumulation consumes): for every window w,
