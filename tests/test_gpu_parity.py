@@ -252,6 +252,24 @@ def test_edge_cases_infinity_cancellation_empty():
     assert curve.jac_from_bytes(bytes(r)) is None
 
 
+def test_scalars_beyond_the_bit_width_do_not_corrupt_memory(dev, torch_cuda):
+    """Scalars >= 2^bits are outside the API contract: the result is unspecified, but the sort must keep
+    every record inside its arrays (the top window's narrower bucket groups clamp) and the next call must be exact."""
+    torch = torch_cuda
+    name = "bn254_snarks_g1"          # 254-bit scalars: bits 254, 255 set -> top-window digits beyond 2^14 buckets
+    n = 50000
+    pts = cref.gen_points(name, 511, n)
+    bad = np.full((n, 32), 0xFF, dtype=np.uint8)
+    bad[::3] = cref.synth_scalars(512, n, 254)[::3]
+    dp = _to_dev(torch, pts)
+    for c in (0, 16, 13):
+        dev.set_option("c", c)
+        dev.msm(name, _to_dev(torch, bad), dp, n, coord="aff")     # must return
+    dev.set_option("c", 0)
+    sc = cref.synth_scalars(513, n, 254)
+    assert bytes(dev.msm(name, _to_dev(torch, sc), dp, n, coord="aff")) == bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
+
+
 def test_all_equal_scalars_one_bucket_per_window():
     """Adversarial distribution: every pair lands in the same bucket -> long head/tail chains + merge tree."""
     from constantine_amd import multiScalarMul_vartime
