@@ -238,6 +238,33 @@ struct HipBackend {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // Tail stream: the narrow (latency-bound) passes at the end of the bucket reduction and the result copy of MSM i run
+  // here, so that the first kernels of MSM i+1 (point conversion, sort: memory- and LDS-bound) run underneath them.
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_tail_fork = nullptr, ev_tail_done = nullptr;
+  bool on_aux = false, tail_pending = false;
+  hipStream_t cur() const { return on_aux ? aux : stream; }
+  void tail_begin() {
+    HIP_CHECK(hipEventRecord(ev_tail_fork, stream));
+    HIP_CHECK(hipStreamWaitEvent(aux, ev_tail_fork, 0));
+    on_aux = true;
+  }
+  void tail_end() {
+    HIP_CHECK(hipEventRecord(ev_tail_done, aux));
+    on_aux = false;
+    tail_pending = true;
+  }
+  // before anything on the main stream touches what a tail still reads or writes (pyramid, trees, per-window output)
+  void tail_wait() {
+    if (!tail_pending) return;
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_tail_done, 0));
+    tail_pending = false;
+  }
+  static uint32_t quad_threshold() {
+    static const uint32_t v = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 24576u;
+    return v;  // measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768
+  }
+  static bool pyr_is_narrow(uint32_t ntasks, uint32_t W) { return (uint64_t)ntasks * W <= quad_threshold(); }
   int num_cu = 256;
   hipEvent_t ev_begin[2][ST_COUNT], ev_end[2][ST_COUNT];  // per in-flight slot
   bool ev_used[2][ST_COUNT];
@@ -263,8 +290,8 @@ struct HipBackend {
   }
   void free_host(void* p) { HIP_CHECK(hipHostFree(p)); }
   void d2h_async(int slot, void* dst_pinned, const void* src, size_t b) {
-    HIP_CHECK(hipMemcpyAsync(dst_pinned, src, b, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipEventRecord(ev_done[slot], stream));
+    HIP_CHECK(hipMemcpyAsync(dst_pinned, src, b, hipMemcpyDeviceToHost, cur()));
+    HIP_CHECK(hipEventRecord(ev_done[slot], cur()));
   }
   void d2h_wait(int slot) { HIP_CHECK(hipEventSynchronize(ev_done[slot])); }
   void d2h_sync(void* dst, const void* src, size_t b) {
@@ -294,7 +321,7 @@ struct HipBackend {
     HIP_CHECK(hipEventRecord(ev_begin[slot][s], stream));
     ev_used[slot][s] = true;
   }
-  void stage_end(int slot, int s) { HIP_CHECK(hipEventRecord(ev_end[slot][s], stream)); }
+  void stage_end(int slot, int s) { HIP_CHECK(hipEventRecord(ev_end[slot][s], cur())); }
   // stage times of the MSM that used `slot` (call after its finish())
   void collect_timings(int slot) {
     for (int i = 0; i < ST_COUNT; i++) {
@@ -354,13 +381,12 @@ struct HipBackend {
   template <class F>
   void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
     // few tasks left: four lanes per addition (the chip is mostly idle, the addition is 3.5x shallower)
-    static const uint32_t quad_env = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 24576u;  // measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768
-    if ((uint64_t)ntasks * W <= quad_env) {
-      hipLaunchKernelGGL(k_pyr_quad<F>, grid2(ntasks * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, ntasks);
+    if (pyr_is_narrow(ntasks, W)) {
+      hipLaunchKernelGGL(k_pyr_quad<F>, grid2(ntasks * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, ntasks);
       HIP_CHECK(hipGetLastError());
       return;
     }
-    hipLaunchKernelGGL(k_pyr<F>, grid2(ntasks, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, ntasks);
+    hipLaunchKernelGGL(k_pyr<F>, grid2(ntasks, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, ntasks);
     HIP_CHECK(hipGetLastError());
   }
 };

@@ -306,9 +306,19 @@ struct MsmEngine {
     XYZZ<FD>* d_pyr = (XYZZ<FD>*)need(rA[0], (size_t)W * B * sizeof(XYZZ<FD>));
     XYZZ<FD>* d_q = (XYZZ<FD>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<FD>));
     XYZZ<FD>* d_out = (XYZZ<FD>*)need(rP[0], (size_t)W * p.c * sizeof(XYZZ<FD>));
+    // The narrow passes at the end (and the result copy) move to the backend's tail stream: they are latency-bound
+    // and the next MSM's conversion and sort fit underneath them.  tail_wait() orders the previous MSM's tail before
+    // this MSM's first write to the pyramid buffers.
+    bk.tail_wait();
+    bool forked = false;
     for (int pass = 0; pass <= p.c - 2; pass++) {
       PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass};
-      bk.template launch_pyr<FD>(pa, W, pyr_pass_tasks(B, p.c, pass));
+      const uint32_t ntasks = pyr_pass_tasks(B, p.c, pass);
+      if (!forked && pass > 0 && bk.pyr_is_narrow(ntasks, W)) {
+        bk.tail_begin();
+        forked = true;
+      }
+      bk.template launch_pyr<FD>(pa, W, ntasks);
     }
     bk.stage_end(sl, ST_REDUCE);
 
@@ -320,6 +330,7 @@ struct MsmEngine {
     }
     bk.d2h_async(sl, S.hraw, d_out, bytes);
     bk.stage_end(sl, ST_TOTAL);
+    if (forked) bk.tail_end();
     return sl;
   }
 
