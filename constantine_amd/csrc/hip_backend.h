@@ -265,6 +265,11 @@ struct HipBackend {
     return v;  // measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768
   }
   static bool pyr_is_narrow(uint32_t ntasks, uint32_t W) { return (uint64_t)ntasks * W <= quad_threshold(); }
+  // passes with at most this many additions (all windows) go to the tail stream
+  static bool pyr_goes_to_tail(uint32_t ntasks, uint32_t W) {
+    static const uint32_t v = getenv("CTT_HIP_MSM_TAIL") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_TAIL")) : 131072u;  // about what fits under the next MSM's conversion + sort (measured 2^20: 3.34 ms at 24576, 3.30 at 131072; above that the tail queues behind the next accumulation)
+    return (uint64_t)ntasks * W <= v;
+  }
   int num_cu = 256;
   hipEvent_t ev_begin[2][ST_COUNT], ev_end[2][ST_COUNT];  // per in-flight slot
   bool ev_used[2][ST_COUNT];

@@ -314,7 +314,7 @@ struct MsmEngine {
     for (int pass = 0; pass <= p.c - 2; pass++) {
       PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass};
       const uint32_t ntasks = pyr_pass_tasks(B, p.c, pass);
-      if (!forked && pass > 0 && bk.pyr_is_narrow(ntasks, W)) {
+      if (!forked && pass > 0 && bk.pyr_goes_to_tail(ntasks, W)) {
         bk.tail_begin();
         forked = true;
       }

@@ -24,7 +24,7 @@ struct EmuBackend {
   void tail_begin() {}
   void tail_end() {}
   void tail_wait() {}
-  static bool pyr_is_narrow(uint32_t, uint32_t) { return false; }
+  static bool pyr_goes_to_tail(uint32_t, uint32_t) { return false; }
   void d2h_sync(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void launch_iota(uint32_t* entries, uint32_t n, uint32_t* bstart, uint32_t* maxcount) {
     for (uint32_t j = 0; j < (n ? n : 1); j++) iota_body(entries, n, bstart, maxcount, j);
