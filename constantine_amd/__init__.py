@@ -7,7 +7,7 @@ Only what the MSM hot path needs lives here:
   msm.py    host-side mirror of the reference's entry points (multiScalarMul_vartime[_parallel],
             Halo2-ZAL CttEngine.msm) over the C ABI
   parallel.py  point-sharded multi-GPU MSM (one process per GPU, torch.distributed / RCCL)
-  kzg.py    the MSM's immediate caller: EIP-4844 blob -> KZG commitment over a cached SRS
+  kzg.py    the MSM's immediate caller: EIP-4844 blob -> KZG commitment and opening proofs over a cached SRS
 """
 from .curves import CURVES, CurveInfo  # noqa: F401
 from .msm import (  # noqa: F401

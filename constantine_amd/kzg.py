@@ -35,6 +35,7 @@ class cttEthKzgStatus(Enum):  # ethereum_eip4844_kzg.nim:87-97 (the members this
     cttEthKzg_EccInvalidEncoding = 5
     cttEthKzg_EccCoordinateGreaterThanOrEqualModulus = 6
     cttEthKzg_EccPointNotOnCurve = 7
+    cttEthKzg_EccPointNotInSubGroup = 8
 
 
 class KzgError(ValueError):
@@ -141,3 +142,123 @@ def blob_to_kzg_commitment(ctx: EthereumKZGContext, blob: bytes) -> bytes:
     poly = blob_to_bigint_polynomial(blob)
     r = ctx._bases.msm(poly, coord="aff")
     return serialize_g1_compressed(_aff_from_mont_bytes(bytes(r)))
+
+
+# ---- proofs: compute_kzg_proof / compute_blob_kzg_proof (ethereum_eip4844_kzg.nim:332-375, :409-444) -------------
+# kzg_prove (commitments/kzg.nim:204-223): quotient polynomial in evaluation form over the bit-reversed roots of unity,
+# then ONE 4096-point MSM against the Lagrange SRS -- the same cached-base MSM as the commitment.  The field
+# arithmetic over Fr (4096 elements, one batched inversion) is host work in plain integers.
+_PRIMITIVE_ROOT_OF_UNITY = 7
+_FIAT_SHAMIR_PROTOCOL_DOMAIN = b"FSBLOBVERIFY_V1_"
+_domain_brp_cache = None
+
+
+def _domain_brp():
+    """The 4096 roots of unity in bit-reversed order (ctx.domain_brp, ethereum_kzg_srs.nim)."""
+    global _domain_brp_cache
+    if _domain_brp_cache is None:
+        w = pow(_PRIMITIVE_ROOT_OF_UNITY, (_R - 1) // FIELD_ELEMENTS_PER_BLOB, _R)
+        roots, x = [], 1
+        for _ in range(FIELD_ELEMENTS_PER_BLOB):
+            roots.append(x)
+            x = x * w % _R
+        _domain_brp_cache = _bit_reversal_permutation(roots)
+    return _domain_brp_cache
+
+
+def _batch_inverse(vals):
+    """Montgomery's trick over Fr; every value must be non-zero."""
+    n = len(vals)
+    pre, run = [0] * n, 1
+    for i, v in enumerate(vals):
+        pre[i] = run
+        run = run * v % _R
+    inv = pow(run, -1, _R)
+    out = [0] * n
+    for i in range(n - 1, -1, -1):
+        out[i] = inv * pre[i] % _R
+        inv = inv * vals[i] % _R
+    return out
+
+
+def _bytes_to_bls_field(b32: bytes) -> int:
+    if len(b32) != 32:
+        raise KzgError(cttEthKzgStatus.cttEthKzg_InputsLengthsMismatch)
+    v = int.from_bytes(b32, "big")
+    if v >= _R:
+        raise KzgError(cttEthKzgStatus.cttEthKzg_ScalarLargerThanCurveOrder)
+    return v
+
+
+def quotient_polynomial(poly, z):
+    """getQuotientPoly (math/polynomials/polynomials.nim): -> (q, y) with y = p(z) and q = (p - y) / (X - z), both in
+    evaluation form over the bit-reversed domain; z may be one of the roots of unity."""
+    dom = _domain_brp()
+    n = FIELD_ELEMENTS_PER_BLOB
+    try:
+        m = dom.index(z)
+    except ValueError:
+        m = -1
+    if m < 0:
+        inv = _batch_inverse([(z - w) % _R for w in dom])                       # 1 / (z - w_i)
+        s = sum(p * w % _R * iv for p, w, iv in zip(poly, dom, inv)) % _R
+        y = (pow(z, n, _R) - 1) * pow(n, -1, _R) % _R * s % _R                     # barycentric evaluation
+        q = [(y - p) * iv % _R for p, iv in zip(poly, inv)]                         # (p_i - y) / (w_i - z)
+        return q, y
+    y = poly[m]
+    others = [i for i in range(n) if i != m]
+    inv = _batch_inverse([(dom[i] - z) % _R for i in others])                      # 1 / (w_i - z)
+    q = [0] * n
+    zinv = pow(z, -1, _R)
+    acc = 0
+    for i, iv in zip(others, inv):
+        q[i] = (poly[i] - y) * iv % _R
+        acc += q[i] * dom[i] % _R * zinv                                           # q_m = - sum q_i * w_i / z
+    q[m] = (-acc) % _R
+    return q, y
+
+
+def _prove(ctx: EthereumKZGContext, blob: bytes, z: int):
+    poly_le = blob_to_bigint_polynomial(blob)
+    poly = [int.from_bytes(bytes(row), "little") for row in poly_le]
+    q, y = quotient_polynomial(poly, z)
+    q_le = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in q), dtype=np.uint8).reshape(FIELD_ELEMENTS_PER_BLOB, 32)
+    r = ctx._bases.msm(q_le, coord="aff")
+    return serialize_g1_compressed(_aff_from_mont_bytes(bytes(r))), y.to_bytes(32, "big")
+
+
+def compute_kzg_proof(ctx: EthereumKZGContext, blob: bytes, z_bytes: bytes):
+    """-> (proof 48 B, y 32 B): [proof]_1 = [(p(tau) - p(z)) / (tau - z)]_1 and y = p(z)."""
+    z = _bytes_to_bls_field(z_bytes)
+    return _prove(ctx, blob, z)
+
+
+def _subgroup_check_g1(ctx: EthereumKZGContext, P):
+    """[r]P == neutral, as a one-pair MSM on the GPU (the reference validates commitments the same way it validates
+    any deserialised point: on the curve and in the prime-order subgroup)."""
+    if P is None:
+        return
+    from .msm import multiScalarMul_vartime
+    r_le = np.frombuffer(_R.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32)
+    pt = np.frombuffer(_aff_mont_bytes(P), dtype=np.uint8).reshape(1, 96)
+    out = multiScalarMul_vartime("bls12_381_g1", r_le, pt, coord="jac")
+    if any(bytes(out[96:144])):
+        raise KzgError(cttEthKzgStatus.cttEthKzg_EccPointNotInSubGroup)
+
+
+def compute_challenge(blob: bytes, commitment_bytes: bytes) -> int:
+    """Fiat-Shamir challenge of the blob proof (`fiatShamirChallenge`, ethereum_eip4844_kzg.nim:126-148):
+    sha256(domain | 16-byte big-endian degree | blob | commitment) reduced mod r."""
+    import hashlib
+    data = (_FIAT_SHAMIR_PROTOCOL_DOMAIN + (0).to_bytes(8, "big") + FIELD_ELEMENTS_PER_BLOB.to_bytes(8, "big")
+            + blob + commitment_bytes)
+    return int.from_bytes(hashlib.sha256(data).digest(), "big") % _R
+
+
+def compute_blob_kzg_proof(ctx: EthereumKZGContext, blob: bytes, commitment_bytes: bytes) -> bytes:
+    """Proof that the blob matches the commitment, at the Fiat-Shamir challenge."""
+    if len(blob) != BYTES_PER_BLOB or len(commitment_bytes) != 48:
+        raise KzgError(cttEthKzgStatus.cttEthKzg_InputsLengthsMismatch)
+    _subgroup_check_g1(ctx, deserialize_g1_compressed(commitment_bytes))
+    blob_to_bigint_polynomial(blob)  # validates the field elements before hashing, as the reference does
+    return _prove(ctx, blob, compute_challenge(blob, commitment_bytes))[0]

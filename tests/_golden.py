@@ -124,3 +124,17 @@ def kzg4844_raw_cases():
             blob = zlib.decompress(base64.b64decode(z))
         out.append((name, blob, None if com is None else bytes.fromhex(com)))
     return out
+
+
+def kzg4844_proof_cases():
+    """-> {"compute_kzg_proof": [(case, blob_bytes, z_bytes, (proof, y) | None)],
+           "compute_blob_kzg_proof": [(case, blob_bytes, commitment_bytes, proof | None)]}"""
+    blobs = {name: blob for name, blob, _ in kzg4844_raw_cases()}
+    doc = json.load(open(os.path.join(HERE, "kzg4844_proofs.json")))
+    out = {"compute_kzg_proof": [], "compute_blob_kzg_proof": []}
+    for case, ref, z, res in doc["compute_kzg_proof"]:
+        out["compute_kzg_proof"].append((case, blobs[ref], bytes.fromhex(z),
+                                         None if res is None else (bytes.fromhex(res[0]), bytes.fromhex(res[1]))))
+    for case, ref, com, res in doc["compute_blob_kzg_proof"]:
+        out["compute_blob_kzg_proof"].append((case, blobs[ref], bytes.fromhex(com), None if res is None else bytes.fromhex(res)))
+    return out

@@ -60,6 +60,47 @@ def main():
             cases.append([os.path.basename(d), base64.b64encode(z).decode(), None])
     json.dump(cases, open(os.path.join(HERE, "kzg4844_blob_to_commitment.json"), "w"), separators=(",", ":"))
     print(len(cases), "cases;", os.path.getsize(os.path.join(HERE, "kzg4844_blob_to_commitment.json")), "bytes")
+    make_proofs(cases)
+
+
+def make_proofs(commit_cases):
+    """compute_kzg_proof / compute_blob_kzg_proof vectors whose blob is one of the blobs kept above (referenced by the
+    name of that case, so no blob is stored twice):
+      tests/protocol_ethereum_eip4844_deneb_kzg/compute_kzg_proof/kzg-mainnet/*/data.yaml
+          -> "compute_kzg_proof": [[case, blob_case, z_hex, [proof_hex, y_hex] | null], ...]
+      tests/protocol_ethereum_eip4844_deneb_kzg/compute_blob_kzg_proof/kzg-mainnet/*/data.yaml
+          -> "compute_blob_kzg_proof": [[case, blob_case, commitment_hex, proof_hex | null], ...]"""
+    import hashlib
+    known = {}
+    for name, z, _ in commit_cases:
+        blob = bytes(int(z[4:])) if z.startswith("LEN:") else zlib.decompress(base64.b64decode(z))
+        if not z.startswith("LEN:"):
+            known[hashlib.sha256(blob).digest()] = name
+    out = {"compute_kzg_proof": [], "compute_blob_kzg_proof": []}
+    root = f"{REF}/tests/protocol_ethereum_eip4844_deneb_kzg"
+    for d in sorted(glob.glob(f"{root}/compute_kzg_proof/kzg-mainnet/*")):
+        t = open(f"{d}/data.yaml").read()
+        blob = bytes.fromhex(re.search(r"blob: '0x([0-9a-f]*)'", t).group(1))
+        z = re.search(r"z: '0x([0-9a-f]*)'", t).group(1)
+        ref = known.get(hashlib.sha256(blob).digest())
+        if ref is None:
+            continue
+        m = re.search(r"output: \['0x([0-9a-f]+)',\s*'0x([0-9a-f]+)'\]", t)
+        assert m or "output: null" in t, d
+        out["compute_kzg_proof"].append([os.path.basename(d), ref, z, [m.group(1), m.group(2)] if m else None])
+    for d in sorted(glob.glob(f"{root}/compute_blob_kzg_proof/kzg-mainnet/*")):
+        t = open(f"{d}/data.yaml").read()
+        blob = bytes.fromhex(re.search(r"blob: '0x([0-9a-f]*)'", t).group(1))
+        com = re.search(r"commitment: '0x([0-9a-f]*)'", t).group(1)
+        ref = known.get(hashlib.sha256(blob).digest())
+        if ref is None:
+            continue
+        m = re.search(r"output: '0x([0-9a-f]+)'", t)
+        assert m or "output: null" in t, d
+        out["compute_blob_kzg_proof"].append([os.path.basename(d), ref, com, m.group(1) if m else None])
+    path = os.path.join(HERE, "kzg4844_proofs.json")
+    json.dump(out, open(path, "w"), separators=(",", ":"))
+    print({k: (len(v), sum(1 for c in v if c[3] is None)) for k, v in out.items()}, "(cases, rejected);", os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
 """EIP-4844 blob_to_kzg_commitment known answers: a 4096-point BLS12-381 G1 MSM through the path
 kzg_commit -> multiScalarMul_vartime (constantine/commitments/kzg.nim:186; vectors from
 tests/protocol_ethereum_eip4844_deneb_kzg/blob_to_kzg_commitment/kzg-mainnet)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -106,5 +108,53 @@ def test_blob_to_kzg_commitment_on_gpu():
                     kzg.blob_to_kzg_commitment(ctx, blob)
             else:
                 assert kzg.blob_to_kzg_commitment(ctx, blob) == com, name
+    finally:
+        ctx.delete()
+
+
+# ---- proofs (compute_kzg_proof / compute_blob_kzg_proof) ---------------------------------------------------------
+def test_quotient_polynomial_evaluations_match_the_reference_vectors():
+    """Host part of kzg_prove: y = p(z) of every valid compute_kzg_proof vector (incl. z = a root of unity and z = 0),
+    and the rejections that are decided before any MSM (z >= r, malformed blob).  No GPU."""
+    from constantine_amd import kzg
+    cases = _golden.kzg4844_proof_cases()["compute_kzg_proof"]
+    seen_root = False
+    for case, blob, zb, res in cases:
+        if res is None:
+            with pytest.raises(kzg.KzgError):
+                z = kzg._bytes_to_bls_field(zb)
+                kzg.blob_to_bigint_polynomial(blob)
+                raise AssertionError(case + ": neither z nor the blob was rejected")
+            continue
+        z = kzg._bytes_to_bls_field(zb)
+        poly = [int.from_bytes(bytes(row), "little") for row in kzg.blob_to_bigint_polynomial(blob)]
+        q, y = kzg.quotient_polynomial(poly, z)
+        assert y.to_bytes(32, "big") == res[1], case
+        seen_root |= z in kzg._domain_brp()
+        # q really is (p - y) / (X - z) on the domain
+        dom = kzg._domain_brp()
+        for i in (0, 1, 777, 4095):
+            assert q[i] * (dom[i] - z) % kzg._R == (poly[i] - y) % kzg._R or dom[i] == z, case
+    assert seen_root, "the vectors include openings at a root of unity"
+
+
+@pytest.mark.gpu
+def test_compute_kzg_proof_vectors_on_gpu():
+    from constantine_amd import kzg
+    ctx = kzg.EthereumKZGContext(open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read())
+    try:
+        cases = _golden.kzg4844_proof_cases()
+        for case, blob, zb, res in cases["compute_kzg_proof"]:
+            if res is None:
+                with pytest.raises(kzg.KzgError):
+                    kzg.compute_kzg_proof(ctx, blob, zb)
+            else:
+                assert kzg.compute_kzg_proof(ctx, blob, zb) == res, case
+        for case, blob, com, res in cases["compute_blob_kzg_proof"]:
+            if res is None:
+                with pytest.raises(kzg.KzgError):
+                    kzg.compute_blob_kzg_proof(ctx, blob, com)
+            else:
+                assert kzg.compute_blob_kzg_proof(ctx, blob, com) == res, case
     finally:
         ctx.delete()
