@@ -52,6 +52,16 @@ def host_cpu_budget():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown CPU"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,7 +218,8 @@ def main():
                 "value": m / cpu_dt, "unit": "points/s", "cores": cores, "kind": "port",
                 "sample": f"first 2^{int(np.log2(m))} pairs of the same workload, oracle/msm_ref.cpp "
                           f"(restatement of Constantine's Pippenger, not Constantine), c={c_used}, {cpu_dt:.2f} s wall, "
-                          f"{cores} threads on a {budget}-CPU cgroup quota ({os.cpu_count()} logical CPUs visible)",
+                          f"{cores} threads on a {budget}-CPU cgroup quota ({os.cpu_count()} logical CPUs visible, {cpu_model()}); "
+                          f"g++ -O3 -march=x86-64-v3, one run",
             }
             out["parity_vs_oracle_on_sample"] = bool(bytes(got) == bytes(exp))
         print(json.dumps(out), flush=True)
