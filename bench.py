@@ -2,7 +2,7 @@
 """
 bench.py -- MSM throughput on MI355X (BASELINE.json metric: MSM points/sec, BLS12-381 G1, 2^20 random pairs).
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -65,8 +65,8 @@ def cpu_model():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--curve", default="bls12_381_g1")
     ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="pairs timed on the CPU baseline")
