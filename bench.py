@@ -3,20 +3,29 @@
 bench.py -- MSM throughput on MI355X (BASELINE.json metric: MSM points/sec, BLS12-381 G1, 2^20 random pairs).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 8 --steps 50 --warmup 5          (starts its own ranks when WORLD_SIZE is unset)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 8 --total-log2n 24                (BASELINE configs[3]: 2^24 pairs over 8 GPUs, strong scaling)
 
 A "step" is one complete MSM (digits -> sort -> bucket accumulation -> bucket reduction -> window combine ->
 affine result on the host) over synthetic inputs that are ALREADY RESIDENT IN HBM when the timed region starts.
-With N GPUs every rank owns 2^20 pairs (weak scaling: the job is one MSM over N*2^20 pairs, sharded by points
+With N GPUs every rank owns 2^log2n pairs (weak scaling: the job is one MSM over N * 2^log2n pairs, sharded by points
 exactly like the reference's msm-level split, ec_multi_scalar_mul_parallel.nim:386-431); each step ends with an
-all_gather of one affine point per rank over RCCL and the host-side sum of the partials.
+all_gather of one affine point per rank over RCCL and the host-side sum of the partials.  --total-log2n fixes the
+whole job instead (strong scaling, 2^total / N pairs per rank).
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).  Beside the pipelined `value` the line
+carries, at N = 1, `latency_ms_blocking` (median wall time of single blocking device-resident calls -- the reference
+bench's definition, one call per iteration, benchmarks/bench_ec_msm_bls12_381_g1.nim:43) and `hostptr_ms` (the same
+through the Constantine symbol on host pointers, PCIe included).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -28,10 +37,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 # v_mad_u64_u32 per mixed addition of the accumulate kernel: 8 products + 2 squares + 9 Montgomery reductions on NL
-# carry-free limbs = 8 NL^2 + NL (NL + 1) + 9 NL^2 (NL = 14 for BLS12-381, 9 for the 254/255-bit fields); DESIGN.md 4.3
-MADS_PER_MIXED_ADD = {"bls12_381_g1": 3542, "bn254_snarks_g1": 1467, "pallas": 1467, "vesta": 1467}
+# carry-free limbs = 8 NL^2 + NL (NL + 1) + 9 NL^2 (NL = 14 for BLS12-381, 9 for the 254/255-bit fields); DESIGN.md 4.3.
+# G2: the same formula over Fp2 -- a product is 4 base products + 2 reductions, a square 2 + 2.
+MADS_PER_MIXED_ADD = {"bls12_381_g1": 3542, "bn254_snarks_g1": 1467, "pallas": 1467, "vesta": 1467,
+                      "bls12_381_g2": 8 * (4 * 196 + 2 * 196) + 2 * (2 * 196 + 2 * 196)}
 INT_MAD_PEAK = 31.0e12         # v_mad_u64_u32 lane-ops/s, measured on MI355X (profiles/microbench_fpu_r01.jsonl: 79.2 G products/s x 393)
 BYTES_PER_PAIR = {"bls12_381_g1": 128, "bn254_snarks_g1": 96, "pallas": 96, "vesta": 96, "bls12_381_g2": 224}
+BASELINE_CONFIG = {("bls12_381_g1", 20, 1): "configs[1]", ("bn254_snarks_g1", 22, 1): "configs[2]",
+                   ("bls12_381_g2", 20, 1): "configs[4]", ("pallas", 20, 1): "configs[4]", ("vesta", 20, 1): "configs[4]"}
 
 
 def host_cpu_budget():
@@ -62,19 +75,42 @@ def cpu_model():
     return "unknown CPU"
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks ourselves (same command line the driver would use)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--curve", default="bls12_381_g1")
-    ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n")
+    ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n (weak scaling)")
+    ap.add_argument("--total-log2n", type=int, default=0, help="total pairs = 2^this, split over the GPUs (strong scaling; "
+                    "BASELINE configs[3] is --gpus 8 --total-log2n 24)")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="pairs timed on the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the blocking-call and host-pointer legs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); gloo is for "
                     "exercising the multi-rank path on a single-GPU box together with --all-ranks-on-device")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="testing: put every rank on this GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -83,7 +119,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if args.all_ranks_on_device >= 0:
         local_rank = args.all_ranks_on_device
@@ -97,19 +133,25 @@ def main():
 
     from constantine_amd import CURVES, DeviceMsm
     from constantine_amd import parallel
-    from oracle import cref  # used ONLY for synthetic scalars (numpy helper) and the cpu_baseline / parity legs
+    from constantine_amd.synth import synth_scalars
 
     curve = args.curve
     info = CURVES[curve]
-    n = 1 << args.log2n
+    strong = args.total_log2n > 0
+    if strong:
+        total = 1 << args.total_log2n
+        first, n = parallel.shard_bounds(total, world, rank)     # balanced contiguous slices (partitioners.nim:44-77)
+    else:
+        n = 1 << args.log2n
+        total = world * n
+        first = rank * n
     seed = 0x5EED0000 + 2  # fixed seed = 0x5EED_0000 + config index
     eng = DeviceMsm(local_rank)
 
     # ---- synthetic inputs, resident in HBM -----------------------------------------------------------
-    first = rank * n
     d_points = torch.empty((n, info.aff_bytes), dtype=torch.uint8, device="cuda")
     eng.gen_points(curve, seed, n, d_points, first=first)            # P_i = [s_i]G, uniform over the subgroup
-    scal = cref.synth_scalars(seed + 1, n, info.scalar_bits, first=first)  # uniform in [0,2^bits), not reduced
+    scal = synth_scalars(seed + 1, n, info.scalar_bits, first=first)  # uniform in [0,2^bits), not reduced
     d_scal = torch.from_numpy(scal).cuda()
     torch.cuda.synchronize()
 
@@ -154,11 +196,13 @@ def main():
 
     plan = eng.last_plan()
     stages = {k: v / args.steps for k, v in stage_acc.items()}
-    value = world * n * args.steps / dt
+    value = total * args.steps / dt
+    lg = args.total_log2n if strong else args.log2n
+    label = BASELINE_CONFIG.get((curve, lg, world)) if not strong else ("configs[3]" if (curve, lg, world) == ("bls12_381_g1", 24, 8) else None)
 
     out = {
-        "metric": "MSM points/sec, BLS12-381 G1, 2^20 random pairs" if (curve == "bls12_381_g1" and args.log2n == 20)
-                  else f"MSM points/sec, {curve}, 2^{args.log2n} random pairs",
+        "metric": "MSM points/sec, BLS12-381 G1, 2^20 random pairs" if (curve == "bls12_381_g1" and lg == 20 and not strong)
+                  else f"MSM points/sec, {curve}, 2^{lg} random pairs" + (" in total" if strong else ""),
         "value": value,
         "unit": "points/s",
         "n_gpus": world,
@@ -166,16 +210,17 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
         "config": {
-            "workload": f"{curve} MSM, 2^{args.log2n} (scalar,point) pairs per GPU, inputs resident in HBM "
-                        f"(BASELINE.json configs[1])",
-            "pairs_per_gpu": n, "total_pairs": world * n, "scalar_bits": info.scalar_bits,
+            "workload": (f"{curve} MSM, 2^{lg} (scalar,point) pairs " + ("in total" if strong else "per GPU")
+                         + ", inputs resident in HBM, two MSMs in flight" + (f" (BASELINE.json {label})" if label else "")),
+            "pairs_per_gpu": n, "total_pairs": total, "scalar_bits": info.scalar_bits,
             "window_bits": plan["c"], "windows": plan["W"], "entries_per_lane": plan["K"],
-            "sharding": f"points x{world}" if world > 1 else "none", "seed": seed,
+            "sharding": f"points x{world}, all_gather of one affine point per rank ({args.backend}) + host sum" if world > 1 else "none",
+            "seed": seed,
         },
         "stage_ms": stages,
     }
@@ -185,16 +230,17 @@ def main():
         t_acc = stages.get("accumulate", 0.0) * 1e-3
         alg_bytes = n * BYTES_PER_PAIR.get(curve, 128)  # N x (scalar + affine point), one launch = all windows
         achieved = alg_bytes / t_acc / 1e9 if t_acc > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         tr_path = os.path.join(ROOT, "profiles", "hbm_traffic_k_accum.json")
         if os.path.exists(tr_path):
             try:
                 traffic = json.load(open(tr_path)).get(f"{curve}_2^{args.log2n}")
+                traffic_src = "profiles/hbm_traffic_k_accum.json (rocprofv3 --pmc passes of an earlier run of this workload, not measured in this run)"
             except Exception:
                 traffic = None
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_accum", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel_ms": stages.get("accumulate", 0.0), "algorithmic_bytes": alg_bytes,
             "note": "integer-VALU bound by construction (no dense contraction); the binding roof is `int_mad` below",
         }
@@ -204,22 +250,58 @@ def main():
                 "instr": "v_mad_u64_u32", "per_launch": mads, "achieved": mads / t_acc / 1e12, "peak": INT_MAD_PEAK / 1e12,
                 "unit": "T lane-ops/s", "frac": mads / t_acc / INT_MAD_PEAK,
             }
+
+    # ---- the reference bench's own definition: one blocking call per iteration ----------------------------
+    if world == 1 and not args.no_latency:
+        lat = []
+        for _ in range(12):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            got_blocking = eng.msm(curve, d_scal, d_points, n, coord="aff")
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat = lat[2:]
+        out["latency_ms_blocking"] = statistics.median(lat)
+        out["latency_note"] = ("median of 10 single blocking ctt_hip_msm_device calls after 2 warm-ups, inputs resident in HBM "
+                               f"(min {min(lat):.3f}, max {max(lat):.3f}); points/s at this latency = {n / statistics.median(lat) * 1e3:.4g}")
+        out["stage_ms_blocking"] = eng.last_timings()
+        # the drop-in symbol itself: host pointers in, PCIe included (never `value`)
+        from constantine_amd import multiScalarMul_vartime, multiScalarMul_vartime_parallel
+        fn = (lambda s, p: multiScalarMul_vartime_parallel(None, curve, s, p, coord="jac")) if info.has_parallel \
+            else (lambda s, p: multiScalarMul_vartime(curve, s, p, coord="jac"))
+        pts_host = d_points.cpu().numpy()
+        hp = []
+        for _ in range(7):
+            t1 = time.perf_counter()
+            fn(scal, pts_host)
+            hp.append((time.perf_counter() - t1) * 1e3)
+        hp = hp[2:]
+        out["hostptr_ms"] = statistics.median(hp)
+        out["hostptr_note"] = (f"median of 5 calls of ctt_{info.sym}_jac_multi_scalar_mul_big_coefs_vartime"
+                               f"{'_parallel' if info.has_parallel else ''} on pageable host arrays after 2 warm-ups "
+                               f"(H2D of {n * (32 + info.aff_bytes) >> 20} MiB included): {n / statistics.median(hp) * 1e3:.4g} points/s")
+
+    if rank == 0:
         # ---- CPU baseline: the oracle port on the host cores, bounded sample; doubles as a parity check -----
         if world == 1 and not args.no_cpu_baseline:
+            from oracle import cref   # the checker: imported for this leg only
             m = min(n, 1 << args.cpu_sample_log2)
             budget = host_cpu_budget()           # the GPU box caps the container at a CPU quota
             cores = min(os.cpu_count() or 1, 2 * budget)  # 2 threads per granted CPU balances the window tasks best
-            pts_host = d_points[:m].cpu().numpy()
-            t1 = time.perf_counter()
-            exp, c_used = cref.msm(curve, scal[:m], pts_host, nthreads=cores)
-            cpu_dt = time.perf_counter() - t1
+            flags = cref.build_native()          # same source rebuilt for this host's CPU (g++ -march=native), else the shipped build
+            pts_m = d_points[:m].cpu().numpy()
+            runs = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                exp, c_used = cref.msm(curve, scal[:m], pts_m, nthreads=cores)
+                runs.append(time.perf_counter() - t1)
+            cpu_dt = statistics.median(runs)
             got = eng.msm(curve, d_scal[:m], d_points[:m], m, coord="aff")
             out["cpu_baseline"] = {
                 "value": m / cpu_dt, "unit": "points/s", "cores": cores, "kind": "port",
                 "sample": f"first 2^{int(np.log2(m))} pairs of the same workload, oracle/msm_ref.cpp "
-                          f"(restatement of Constantine's Pippenger, not Constantine), c={c_used}, {cpu_dt:.2f} s wall, "
-                          f"{cores} threads on a {budget}-CPU cgroup quota ({os.cpu_count()} logical CPUs visible, {cpu_model()}); "
-                          f"g++ -O3 -march=x86-64-v3, one run",
+                          f"(restatement of Constantine's Pippenger, not Constantine), c={c_used}, median of 3 runs "
+                          f"({', '.join(f'{r:.2f}' for r in runs)} s wall), "
+                          f"{cores} threads on a {budget}-CPU cgroup quota ({os.cpu_count()} logical CPUs visible, {cpu_model()}); {flags}",
             }
             out["parity_vs_oracle_on_sample"] = bool(bytes(got) == bytes(exp))
         print(json.dumps(out), flush=True)

@@ -6,7 +6,9 @@ Only what the MSM hot path needs lives here:
   _lib.py   ctypes loader (fails loudly if the HIP library is missing)
   msm.py    host-side mirror of the reference's entry points (multiScalarMul_vartime[_parallel],
             Halo2-ZAL CttEngine.msm) over the C ABI
-  parallel.py  point-sharded multi-GPU MSM (one process per GPU, torch.distributed / RCCL)
+  parallel.py  point-sharded multi-GPU MSM, one process per GPU (torch.distributed / RCCL); the in-library form, one
+            process driving several GPUs, is ctt_hip_msm_set_devices / $CTT_HIP_DEVICES (msm.set_devices)
+  synth.py  synthetic benchmark inputs (seeded scalars)
   kzg.py    the MSM's immediate caller: EIP-4844 blob -> KZG commitment and opening proofs over a cached SRS
 """
 from .curves import CURVES, CurveInfo  # noqa: F401
@@ -18,4 +20,6 @@ from .msm import (  # noqa: F401
     sum_reduce_vartime,
     multiScalarMul_vartime,
     multiScalarMul_vartime_parallel,
+    set_devices,
+    set_shard_min,
 )

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTT_MSM_HIP_LIB") or os.path.join(HERE, "libctt_msm_hip.so")
 
 _lib = None
-ABI_VERSION = 2  # ctt_hip_msm_abi_version() of the library this package was written against
+ABI_VERSION = 3  # ctt_hip_msm_abi_version() of the library this package was written against
 
 
 class HipLibraryMissing(RuntimeError):
@@ -27,7 +27,8 @@ def exported_symbols():
     syms += ["ctt_hip_sum_reduce", "ctt_hip_batch_affine", "ctt_hip_msm_abi_version", "ctt_hip_msm_ctx_create", "ctt_hip_msm_ctx_destroy", "ctt_hip_msm_set_option",
              "ctt_hip_msm_device", "ctt_hip_msm_device_submit", "ctt_hip_msm_device_finish", "ctt_hip_msm_sync", "ctt_hip_msm_bases_create", "ctt_hip_msm_bases_destroy",
              "ctt_hip_msm_with_bases", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
-             "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream"]
+             "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream", "ctt_hip_msm_wait_stream",
+             "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min"]
     return syms
 
 
@@ -96,5 +97,9 @@ def lib():
     L.ctt_hip_ec_sum_affine.argtypes = [i32, i32, vp, vp, sz]
     L.ctt_hip_msm_stream.argtypes = [vp]
     L.ctt_hip_msm_stream.restype = vp
+    L.ctt_hip_msm_wait_stream.argtypes = [vp, vp]
+    L.ctt_hip_msm_set_devices.argtypes = [ctypes.POINTER(i32), i32]
+    L.ctt_hip_msm_set_shard_min.argtypes = [sz]
+    L.ctt_hip_msm_set_shard_min.restype = None
     _lib = L
     return L

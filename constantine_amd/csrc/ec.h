@@ -12,7 +12,7 @@
 //
 // The formulas are written once for both field flavours.  For the carry-free field (fpu.h) values are only
 // bounded by multiples of p, tracked statically here in units of M = F::MULB (a product is < M*p):
-//     affine input x, y < M;   stored XYZZ:  X < 4M,  Y < 2M,  ZZ, ZZZ < M.
+//     affine input x, y < M;   stored XYZZ:  X < 4M + 1 (xyzz_madd, see XYZZ_XB),  Y < 2M,  ZZ, ZZZ < M.
 // fsub<F,B>(a,b) = a - b + B*p needs b < B*p and yields bound(a)+B; the canonical field ignores B.
 #pragma once
 #include "fpu.h"
@@ -80,32 +80,39 @@ CTT_HD XYZZ<F> xyzz_madd_same_x(const F& qx, const F& qy, bool same_y) {
   return XYZZ<F>::inf();
 }
 
-// acc += (neg ? -q : q), q affine
+// acc += (neg ? -q : q), q affine -- the hot function (one call per (window, pair)).
+// Bounds below are in units of p.  In: q.x, q.y < 2; acc.x < XB = 9, acc.y < 4, acc.zz, acc.zzz < 2.  Out: the same.
+// Values that only feed products are left lazy (fpu.h "lazy forms") where the field's column budget allows it:
+// L1 = a lazy operand against a normalised one, L2 = lazy against lazy (28-bit limbs only).
+static constexpr int XYZZ_XB = 9;  // stored X < 9p (xyzz_madd's X3 = RR - PPP - 2Q + 7p); the other formulas give < 8p
 template <class F>
 CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
-  constexpr int M = F::MULB;
+  constexpr int M = F::MULB;                                  // a product is < M*p, M = 2
+  constexpr bool L1 = LazyOps<F>::ONE, L2 = LazyOps<F>::BOTH;
+  constexpr int XB = XYZZ_XB;
   if (q.is_inf()) return;
-  F qy = fcneg<F, M>(q.y, neg);                  // < M
+  F qy = fcneg_lz<F, M, L1>(q.y, neg);                        // < 3, lazy: feeds S2 only (and the rare paths)
   if (acc.is_inf()) {
     acc.x = q.x;
-    acc.y = qy;
+    acc.y = fcneg<F, M>(q.y, neg);                            // normalised, < 2
     acc.zz = F::one();
     acc.zzz = F::one();
     return;
   }
   F U2, S2;
-  fmul_pair<F>(q.x, acc.zz, qy, acc.zzz, U2, S2);  // < M
-  F P = fsub<F, 4 * M>(U2, acc.x);               // < 5M
-  F R = fsub<F, 2 * M>(S2, acc.y);               // < 3M
-  if (fis_zero_modp<F, 5 * M>(P)) {              // P == +-Q: rare, out of line
-    acc = xyzz_madd_same_x<F>(q.x, qy, fis_zero_modp<F, 3 * M>(R));
+  fmul_pair<F>(q.x, acc.zz, qy, acc.zzz, U2, S2);             // 2*2, 3*2
+  F P = fsub_lz<F, XB, L2>(U2, acc.x);                        // < 2 + 10 = 12; feeds P^2, P*PP
+  F R = fsub_lz<F, 2 * M, L2>(S2, acc.y);                     // < 2 + 5 = 7;   feeds R^2, R*T
+  if (fis_zero_modp<F, M + XB + 1>(P)) {                      // P == +-Q: rare, out of line
+    acc = xyzz_madd_same_x<F>(q.x, fcneg<F, M>(q.y, neg), fis_zero_modp<F, 3 * M + 1>(R));
     return;
   }
   F PP, RR, PPP, Q;
-  fsqr_pair<F>(P, R, PP, RR);
-  fmul_pair<F>(P, PP, acc.x, PP, PPP, Q);
-  F X3 = fsub<F, 2 * M>(fsub<F, M>(RR, PPP), F::dbl(Q));               // < 4M
-  F Y3 = fmul_sub<F, 2 * M>(R, fsub<F, 4 * M>(Q, X3), acc.y, PPP);     // R*(Q-X3) - Y1*PPP, < 2M
+  fsqr_pair<F>(P, R, PP, RR);                                 // 144, 49   (121, 36 when P, R are normalised: < 128)
+  fmul_pair<F>(P, PP, acc.x, PP, PPP, Q);                     // 24, 18
+  F X3 = fsub3<F, 7>(RR, PPP, Q);                             // RR - PPP - 2Q + 7p < 9   (PPP + 2Q < 6)
+  F T = fsub_lz<F, XB, L1>(Q, X3);                            // Q - X3 + 10p < 12; feeds R*T (R lazy only when L2)
+  F Y3 = fmul_sub_lz<F, 2 * M, L1>(R, T, acc.y, PPP);         // R*T - Y1*PPP: 7*12 + 5*2 = 94; < 2
   acc.x = X3;
   acc.y = Y3;
   F Z2, Z3;

@@ -17,6 +17,8 @@
 // Conversions to/from the reference's representation (Montgomery R = 2^(64L), saturated limbs) happen once per
 // point on the way in (from_sat) and once per returned point on the host (HostField, host_fp64.h).
 #pragma once
+#include <type_traits>
+
 #include "fp.h"
 
 namespace ctt {
@@ -74,34 +76,30 @@ struct FpU {
     return r;
   }
 
-  // value == 0 (mod p), for a normalised element known to be < B*p
+  // value == 0 (mod p), for an element known to be < B*p (B < 2^LB); the limbs may be lazy (sub_lazy).
+  // v = k*p  =>  v * (-1/p) == -k (mod 2^LB), and M0INV is -1/p mod 2^LB: one multiplication of the low limb gives the
+  // only k the value could be a multiple by; k >= B rejects (all but B in 2^LB values), else compare against k*p.
   template <int B>
   CTT_HD bool is_zero_modp() const {
-    // quick reject on the low limb: v = k*p  =>  l[0] == (k*p) mod 2^LB for some k < B
-    bool maybe = false;
-#pragma unroll
-    for (int k = 0; k < B; k++) maybe |= (l[0] == kp(k).l[0]);
-    if (!maybe) return false;
+    const uint32_t k = (0u - l[0] * UP::M0INV) & MASK;
+    if (k >= (uint32_t)B) return false;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" ::: "memory");  // keep the full comparison behind a real branch (hipcc otherwise speculates it)
 #endif
-    return is_multiple_of_p(*this, B);
+    return equals_kp(*this, k);
   }
-  // rare path, kept out of line: compare against k*p limb by limb
-  static CTT_HD bool is_multiple_of_p(const FpU& a, int B) {
-    bool hit = false;
-    for (int k = 0; k < B; k++) {
-      uint32_t d = 0;
-      uint64_t c = 0;
-      for (int i = 0; i < NL; i++) {
-        uint64_t v = (uint64_t)UP::P[i] * (uint64_t)k + c;
-        uint32_t li = (i == NL - 1) ? (uint32_t)v : (uint32_t)(v & MASK);
-        c = v >> LB;
-        d |= a.l[i] ^ li;
-      }
-      hit |= (d == 0);
+  // rare path: a == k*p exactly (a is normalised here first)
+  static CTT_HD bool equals_kp(FpU a, uint32_t k) {
+    a.normalise();
+    uint32_t d = 0;
+    uint64_t c = 0;
+    for (int i = 0; i < NL; i++) {
+      uint64_t v = (uint64_t)UP::P[i] * (uint64_t)k + c;
+      uint32_t li = (i == NL - 1) ? (uint32_t)v : (uint32_t)(v & MASK);
+      c = v >> LB;
+      d |= a.l[i] ^ li;
     }
-    return hit;
+    return d == 0;
   }
 
   // carry propagation: limbs < 2^LB afterwards (the top limb keeps the excess)
@@ -152,116 +150,289 @@ struct FpU {
     return select(c, n, a);
   }
 
+  // ---- lazy forms: no carry propagation --------------------------------------------------------------------------
+  // sub_lazy<B>(a, b) = a - b + (B+1)*p with every limb left as a_i + bias_i - b_i (< 3*2^LB): half the instructions of
+  // sub<B>.  Valid ONLY as an operand of a product (never stored, never an operand of add/sub); a and b normalised,
+  // b < B*p.  The bias is (B+1)*p, one multiple more than sub<B> takes, so that the top limb cannot go negative
+  // before the carries that normalise() would have delivered.  Value < bound(a) + B + 1.
+  // Which products may take lazy operands is a matter of the 64-bit column sums (limbs l_a, l_b; NL terms each):
+  //   LAZY_ONE   (lazy x normal) + (lazy x normal) + reduction:   (3 + 3 + 1) * NL * 2^(2 LB) < 2^64
+  //   LAZY_BOTH  (lazy x lazy)   + (lazy x normal) + reduction:   (9 + 3 + 1) * NL * 2^(2 LB) < 2^64
+  static constexpr bool LAZY_ONE = 7ull * NL <= (1ull << (64 - 2 * LB)) - 1;
+  static constexpr bool LAZY_BOTH = 13ull * NL <= (1ull << (64 - 2 * LB)) - 1;
+  static_assert(UP::P[NL - 1] >= 8u, "top limb of p too small for the lazy bias arithmetic");
+  template <int B>
+  CTT_HD static FpU sub_lazy(const FpU& a, const FpU& b) {
+    constexpr KP c = kp(B + 1);
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const uint32_t bias = (i == 0) ? c.l[0] + (1u << LB) : (i == NL - 1) ? c.l[i] - 1u : c.l[i] + (1u << LB) - 1u;
+      r.l[i] = a.l[i] + bias - b.l[i];
+    }
+    return r;
+  }
+  // conditional negation, lazy in the negated branch: (B+1)*p - a  (a < B*p, normalised)
+  template <int B>
+  CTT_HD static FpU cneg_lazy(const FpU& a, bool c) {
+    return select(c, sub_lazy<B>(zero(), a), a);
+  }
+  CTT_HD static FpU norm(const FpU& a) {
+    FpU r = a;
+    r.normalise();
+    return r;
+  }
+  // a - b - 2c + K*p, normalised, in one pass (the X3 of the addition formulas: RR - PPP - 2Q).
+  // Needs b + 2c < (K-1)*p; every limb gets 3*2^LB on loan from the next one.  Value < bound(a) + K.
+  template <int K>
+  CTT_HD static FpU sub3(const FpU& a, const FpU& b, const FpU& c) {
+    constexpr KP kpv = kp(K);
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const uint32_t bias = (i == 0) ? kpv.l[0] + (3u << LB) : (i == NL - 1) ? kpv.l[i] - 3u : kpv.l[i] + (3u << LB) - 3u;
+      r.l[i] = a.l[i] + bias - b.l[i] - (c.l[i] << 1);
+    }
+    r.normalise();
+    return r;
+  }
+
+  // ---- column accumulation --------------------------------------------------------------------------------
+  // A product-scanning column is a chain acc = a_i*b_j + acc of v_mad_u64_u32 whose 64-bit addend is the running
+  // sum, the previous column's carry (acc >> LB) included.  Written as plain C++ the compiler re-associates every
+  // column (its Reassociate pass ranks the carry last): it starts a fresh chain from 0 and adds the carry at the end
+  // with a separate 64-bit addition (v_lshl_add_u64, as expensive as a multiply) -- one extra quarter-rate
+  // instruction per column, 243 per mixed addition.  CTT_FPU_CHAIN != 0 spells the chain out as inline asm so that
+  // the carry IS the first addend, with up to CTT_FPU_CHAIN (1..8) multiply-adds per asm statement.
+  // The host build (tests/emu, window combine) always takes the C++ form.
+#ifndef CTT_FPU_CHAIN
+#define CTT_FPU_CHAIN 4
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && CTT_FPU_CHAIN
+#define CTT_FPU_ASM 1
+#define CTT_MADU(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\t"
+  // 1..8 dependent multiply-adds into acc per statement (hipcc pads every asm statement with one s_nop)
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0) {
+    asm(CTT_MADU(1, 2)
+        : "+v"(acc) : "v"(a0), "v"(b0) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7) : "vcc");
+  }
+  // second factor = a constant of the field (an SGPR; gfx9 VOP3 reads one SGPR per instruction)
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0) {
+    asm(CTT_MADU(1, 2)
+        : "+v"(acc) : "v"(a0), "s"(b0) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7) : "vcc");
+  }
+#else
+#define CTT_FPU_ASM 0
+#endif
+
+  // acc += sum_{i = LO}^{HI-1} a[i] * b[K-i]    (all bounds compile-time: the columns are unrolled by templates)
+  static constexpr int GROUP = CTT_FPU_CHAIN < 1 ? 1 : CTT_FPU_CHAIN > 8 ? 8 : CTT_FPU_CHAIN;  // multiply-adds per asm statement
+  template <int K, int LO, int HI>
+  CTT_HD static void col_ab(uint64_t& acc, const uint32_t* a, const uint32_t* b) {
+    if constexpr (LO < HI) {
+#if CTT_FPU_ASM
+      constexpr int R = HI - LO < GROUP ? HI - LO : GROUP;
+#define CTT_AB(j) a[LO + j], b[K - LO - j]
+      if constexpr (R == 8) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6), CTT_AB(7));
+      else if constexpr (R == 7) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6));
+      else if constexpr (R == 6) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5));
+      else if constexpr (R == 5) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4));
+      else if constexpr (R == 4) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3));
+      else if constexpr (R == 3) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2));
+      else if constexpr (R == 2) madv(acc, CTT_AB(0), CTT_AB(1));
+      else madv(acc, CTT_AB(0));
+#undef CTT_AB
+      col_ab<K, LO + R, HI>(acc, a, b);
+#else
+      acc += (uint64_t)a[LO] * b[K - LO];
+      col_ab<K, LO + 1, HI>(acc, a, b);
+#endif
+    }
+  }
+  // number of leading non-zero limbs P[K-LO], P[K-LO-1], ... (at most GROUP, at most HI-LO)
+  template <int K, int LO, int HI>
+  static constexpr int nz_run() {
+    int n = 0;
+    for (int i = LO; i < HI && n < GROUP; i++) {
+      if (UP::P[K - i] == 0u) break;
+      n++;
+    }
+    return n;
+  }
+  // acc += sum_{i = LO}^{HI-1} m[i] * P[K-i]   (zero limbs of P are skipped: the Pasta primes have three)
+  template <int K, int LO, int HI>
+  CTT_HD static void col_mp(uint64_t& acc, const uint32_t* m) {
+    if constexpr (LO < HI) {
+      if constexpr (UP::P[K - LO] == 0u) {
+        col_mp<K, LO + 1, HI>(acc, m);
+      } else {
+#if CTT_FPU_ASM
+        constexpr int R = nz_run<K, LO, HI>();
+#define CTT_MP(j) m[LO + j], UP::P[K - LO - j]
+        if constexpr (R == 8) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6), CTT_MP(7));
+        else if constexpr (R == 7) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6));
+        else if constexpr (R == 6) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5));
+        else if constexpr (R == 5) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4));
+        else if constexpr (R == 4) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3));
+        else if constexpr (R == 3) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2));
+        else if constexpr (R == 2) mads(acc, CTT_MP(0), CTT_MP(1));
+        else mads(acc, CTT_MP(0));
+#undef CTT_MP
+        col_mp<K, LO + R, HI>(acc, m);
+#else
+        acc += (uint64_t)m[LO] * UP::P[K - LO];
+        col_mp<K, LO + 1, HI>(acc, m);
+#endif
+      }
+    }
+  }
+  CTT_HD static void mad1(uint64_t& acc, uint32_t a, uint32_t b) {
+#if CTT_FPU_ASM
+    madv(acc, a, b);
+#else
+    acc += (uint64_t)a * b;
+#endif
+  }
+  CTT_HD static void mad1k(uint64_t& acc, uint32_t a, uint32_t k) {
+#if CTT_FPU_ASM
+    mads(acc, a, k);
+#else
+    acc += (uint64_t)a * k;
+#endif
+  }
+  // products of column K of a*b
+  template <int K>
+  CTT_HD static void col_prod(uint64_t& acc, const uint32_t* a, const uint32_t* b) {
+    col_ab<K, (K < NL ? 0 : K - NL + 1), (K < NL ? K + 1 : NL)>(acc, a, b);
+  }
+  // column K of a square: cross products once, sum_{i < K-i} (2 a_i) a_{K-i}, then the diagonal term when K is even
+  template <int K>
+  CTT_HD static void col_sq(uint64_t& acc, const uint32_t* a, const uint32_t* a2) {
+    col_ab<K, (K - NL + 1 > 0 ? K - NL + 1 : 0), ((K + 1) >> 1)>(acc, a2, a);
+    if constexpr ((K & 1) == 0) mad1(acc, a[K >> 1], a[K >> 1]);
+  }
+  // Montgomery part of column K: the products of the quotient digits known so far with P; for K < NL the new digit
+  // m[K] and its product with P[0] (the low LB bits of the column then vanish); for K >= NL the result limb.
+  // Ends with the carry into the next column.
+  template <int K>
+  CTT_HD static void col_finish(uint64_t& acc, uint32_t* m, uint32_t* t) {
+    col_mp<K, (K < NL ? 0 : K - NL + 1), (K < NL ? K : NL)>(acc, m);
+    if constexpr (K < NL) {
+      m[K] = ((uint32_t)acc * UP::M0INV) & MASK;
+      mad1k(acc, m[K], UP::P[0]);
+    } else {
+      t[K - NL] = (uint32_t)acc & MASK;
+    }
+    acc >>= LB;
+  }
+  // compile-time loop over the columns
+  template <int K, int END, class Fn>
+  CTT_HD static void columns(Fn&& f) {
+    if constexpr (K < END) {
+      f(std::integral_constant<int, K>{});
+      columns<K + 1, END>(f);
+    }
+  }
+#define CTT_COL_LAMBDA(kc) [&](auto kc) __attribute__((always_inline))
+
   // Montgomery product a*b/R' (mod p), radix 2^LB, product scanning; limbs of a, b < 2^30, a*b < R'*p.
   CTT_HD static FpU mul(const FpU& a, const FpU& b) {
     uint64_t acc = 0;
     uint32_t m[NL];
     FpU t;
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-#pragma unroll
-      for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-      for (int i = 0; i < k; i++)
-        if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
-      m[k] = ((uint32_t)acc * UP::M0INV) & MASK;
-      acc += (uint64_t)m[k] * UP::P[0];
-      acc >>= LB;
-    }
-#pragma unroll
-    for (int k = NL; k < 2 * NL - 1; k++) {
-#pragma unroll
-      for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-      for (int i = k - NL + 1; i < NL; i++)
-        if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
-      t.l[k - NL] = (uint32_t)acc & MASK;
-      acc >>= LB;
-    }
+    columns<0, 2 * NL - 1>(CTT_COL_LAMBDA(kc) {
+      constexpr int k = decltype(kc)::value;
+      col_prod<k>(acc, a.l, b.l);
+      col_finish<k>(acc, m, t.l);
+    });
     t.l[NL - 1] = (uint32_t)acc;
     return t;
   }
 
   // (a*b + c*d)/R' (mod p): two products, one Montgomery reduction.  Needs a*b + c*d < R'*p.
-  // The two products run in separate column accumulators (two dependency chains, see mul_pair).
   CTT_HD static FpU mul2(const FpU& a, const FpU& b, const FpU& c, const FpU& d) {
     uint64_t acc = 0;
     uint32_t m[NL];
     FpU t;
-#pragma unroll
-    for (int k = 0; k < 2 * NL - 1; k++) {
-      uint64_t s2 = 0;
-#pragma unroll
-      for (int i = 0; i < NL; i++) {
-        const int j = k - i;
-        if (j >= 0 && j < NL) {
-          acc += (uint64_t)a.l[i] * b.l[j];
-          s2 += (uint64_t)c.l[i] * d.l[j];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NL; i++) {
-        const int j = k - i;
-        if (j >= 1 && j < NL && i < (k < NL ? k : NL) && UP::P[j] != 0u) s2 += (uint64_t)m[i] * UP::P[j];
-      }
-      acc += s2;
-      if (k < NL) {
-        m[k] = ((uint32_t)acc * UP::M0INV) & MASK;
-        acc += (uint64_t)m[k] * UP::P[0];
-      } else {
-        t.l[k - NL] = (uint32_t)acc & MASK;
-      }
-      acc >>= LB;
-    }
+    columns<0, 2 * NL - 1>(CTT_COL_LAMBDA(kc) {
+      constexpr int k = decltype(kc)::value;
+      col_prod<k>(acc, a.l, b.l);
+      col_prod<k>(acc, c.l, d.l);
+      col_finish<k>(acc, m, t.l);
+    });
     t.l[NL - 1] = (uint32_t)acc;
     return t;
   }
 
   // Two independent products written column by column side by side: a single product is one long dependency
   // chain through its column accumulator; a second, independent chain gives the in-order issue logic something to
-  // do while a v_mad_u64_u32 result is in flight.  hipcc is left to schedule the two chains (pinning the order
-  // with sched_barrier or two-instruction asm statements measured slower: 2.66 vs 2.52 ms on the accumulate kernel).
+  // do while a v_mad_u64_u32 result is in flight.  hipcc is left to schedule the two chains.
   CTT_HD static void mul_pair(const FpU& a, const FpU& b, const FpU& c, const FpU& d, FpU& r1, FpU& r2) {
     uint64_t acc1 = 0, acc2 = 0;
     uint32_t m1[NL], m2[NL];
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-#pragma unroll
-      for (int i = 0; i <= k; i++) {
-        acc1 += (uint64_t)a.l[i] * b.l[k - i];
-        acc2 += (uint64_t)c.l[i] * d.l[k - i];
-      }
-#pragma unroll
-      for (int i = 0; i < k; i++)
-        if (UP::P[k - i] != 0u) {
-          acc1 += (uint64_t)m1[i] * UP::P[k - i];
-          acc2 += (uint64_t)m2[i] * UP::P[k - i];
-        }
-      m1[k] = ((uint32_t)acc1 * UP::M0INV) & MASK;
-      m2[k] = ((uint32_t)acc2 * UP::M0INV) & MASK;
-      acc1 += (uint64_t)m1[k] * UP::P[0];
-      acc2 += (uint64_t)m2[k] * UP::P[0];
-      acc1 >>= LB;
-      acc2 >>= LB;
-    }
-#pragma unroll
-    for (int k = NL; k < 2 * NL - 1; k++) {
-#pragma unroll
-      for (int i = k - NL + 1; i < NL; i++) {
-        acc1 += (uint64_t)a.l[i] * b.l[k - i];
-        acc2 += (uint64_t)c.l[i] * d.l[k - i];
-      }
-#pragma unroll
-      for (int i = k - NL + 1; i < NL; i++)
-        if (UP::P[k - i] != 0u) {
-          acc1 += (uint64_t)m1[i] * UP::P[k - i];
-          acc2 += (uint64_t)m2[i] * UP::P[k - i];
-        }
-      r1.l[k - NL] = (uint32_t)acc1 & MASK;
-      r2.l[k - NL] = (uint32_t)acc2 & MASK;
-      acc1 >>= LB;
-      acc2 >>= LB;
-    }
+    columns<0, 2 * NL - 1>(CTT_COL_LAMBDA(kc) {
+      constexpr int k = decltype(kc)::value;
+      col_prod<k>(acc1, a.l, b.l);
+      col_prod<k>(acc2, c.l, d.l);
+      col_finish<k>(acc1, m1, r1.l);
+      col_finish<k>(acc2, m2, r2.l);
+    });
     r1.l[NL - 1] = (uint32_t)acc1;
     r2.l[NL - 1] = (uint32_t)acc2;
   }
@@ -275,45 +446,13 @@ struct FpU {
       a2[i] = a.l[i] << 1;
       c2[i] = c.l[i] << 1;
     }
-#pragma unroll
-    for (int k = 0; k < 2 * NL - 1; k++) {
-      {
-        const int lo = k - NL + 1 > 0 ? k - NL + 1 : 0;
-        const int hi = (k + 1) >> 1;  // i < j  <=>  i < (k+1)/2
-#pragma unroll
-        for (int i = lo; i < hi; i++) {
-          acc1 += (uint64_t)a2[i] * a.l[k - i];
-          acc2 += (uint64_t)c2[i] * c.l[k - i];
-        }
-      }
-      if ((k & 1) == 0) {
-        acc1 += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
-        acc2 += (uint64_t)c.l[k >> 1] * c.l[k >> 1];
-      }
-      if (k < NL) {
-#pragma unroll
-        for (int i = 0; i < k; i++)
-          if (UP::P[k - i] != 0u) {
-            acc1 += (uint64_t)m1[i] * UP::P[k - i];
-            acc2 += (uint64_t)m2[i] * UP::P[k - i];
-          }
-        m1[k] = ((uint32_t)acc1 * UP::M0INV) & MASK;
-        m2[k] = ((uint32_t)acc2 * UP::M0INV) & MASK;
-        acc1 += (uint64_t)m1[k] * UP::P[0];
-        acc2 += (uint64_t)m2[k] * UP::P[0];
-      } else {
-#pragma unroll
-        for (int i = k - NL + 1; i < NL; i++)
-          if (UP::P[k - i] != 0u) {
-            acc1 += (uint64_t)m1[i] * UP::P[k - i];
-            acc2 += (uint64_t)m2[i] * UP::P[k - i];
-          }
-        r1.l[k - NL] = (uint32_t)acc1 & MASK;
-        r2.l[k - NL] = (uint32_t)acc2 & MASK;
-      }
-      acc1 >>= LB;
-      acc2 >>= LB;
-    }
+    columns<0, 2 * NL - 1>(CTT_COL_LAMBDA(kc) {
+      constexpr int k = decltype(kc)::value;
+      col_sq<k>(acc1, a.l, a2);
+      col_sq<k>(acc2, c.l, c2);
+      col_finish<k>(acc1, m1, r1.l);
+      col_finish<k>(acc2, m2, r2.l);
+    });
     r1.l[NL - 1] = (uint32_t)acc1;
     r2.l[NL - 1] = (uint32_t)acc2;
   }
@@ -321,34 +460,15 @@ struct FpU {
   // square: cross products once with a doubled operand (2*a_i < 2^31 fits)
   CTT_HD static FpU sqr(const FpU& a) {
     uint64_t acc = 0;
-    uint32_t m[NL];
-    uint32_t a2[NL];
+    uint32_t m[NL], a2[NL];
     FpU t;
 #pragma unroll
     for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
-#pragma unroll
-    for (int k = 0; k < 2 * NL - 1; k++) {
-      {
-        const int lo = k - NL + 1 > 0 ? k - NL + 1 : 0;
-        const int hi = (k + 1) >> 1;  // i < j  <=>  i < (k+1)/2
-#pragma unroll
-        for (int i = lo; i < hi; i++) acc += (uint64_t)a2[i] * a.l[k - i];
-      }
-      if ((k & 1) == 0) acc += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
-      if (k < NL) {
-#pragma unroll
-        for (int i = 0; i < k; i++)
-          if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
-        m[k] = ((uint32_t)acc * UP::M0INV) & MASK;
-        acc += (uint64_t)m[k] * UP::P[0];
-      } else {
-#pragma unroll
-        for (int i = k - NL + 1; i < NL; i++)
-          if (UP::P[k - i] != 0u) acc += (uint64_t)m[i] * UP::P[k - i];
-        t.l[k - NL] = (uint32_t)acc & MASK;
-      }
-      acc >>= LB;
-    }
+    columns<0, 2 * NL - 1>(CTT_COL_LAMBDA(kc) {
+      constexpr int k = decltype(kc)::value;
+      col_sq<k>(acc, a.l, a2);
+      col_finish<k>(acc, m, t.l);
+    });
     t.l[NL - 1] = (uint32_t)acc;
     return t;
   }
@@ -378,8 +498,9 @@ struct FpU {
 // element (MULB = 2: products come out of ONE Montgomery reduction each, < 2p):
 //   mul:  c0 = a0*b0 + (Kp - a1)*b1,  c1 = a0*b1 + a1*b0        (two sum-of-products, towers.nim:852-878 prod2x)
 //   sqr:  c0 = (a0 + a1)*(a0 - a1 + Kp),  c1 = a0*a1 + a0*a1    (square_complex, towers.nim:758-796)
-// K = 10 covers every operand the EC formulas produce (components < 5*MULB*p); needs 2*K^2 < R'/p, true for
-// BLS12-381 (R'/p = 2^11), not for the 29x9 fields.
+// K = 12 covers every operand the EC formulas produce (components < 12p, ec.h); needs 2*K^2 < R'/p, true for
+// BLS12-381 (R'/p = 2^11), not for the 29x9 fields.  No lazy operands here: two sum-of-products per column already
+// use the 64-bit column budget.
 // ---------------------------------------------------------------------------------------------
 template <class UP>
 struct Fp2<FpU<UP>> {
@@ -387,7 +508,7 @@ struct Fp2<FpU<UP>> {
   using Base = F;
   static constexpr int MULB = 2;
   static constexpr bool UNSAT = true;
-  static constexpr int KNEG = 10;
+  static constexpr int KNEG = 12;
   static constexpr int HEADROOM_LOG2 = UP::RP_OVER_P_LOG2;  // log2(R'/p): operand bounds k1*k2 must stay below it
   static constexpr int LB = F::LB;
   static constexpr int NL = 2 * F::NL;   // limbs of the whole element (c0 then c1)
@@ -413,6 +534,10 @@ struct Fp2<FpU<UP>> {
   template <int B>
   CTT_HD static Fp2 cneg(const Fp2& a, bool c) {
     return {F::template cneg<B>(a.c0, c), F::template cneg<B>(a.c1, c)};
+  }
+  template <int K>
+  CTT_HD static Fp2 sub3(const Fp2& a, const Fp2& b, const Fp2& c) {
+    return {F::template sub3<K>(a.c0, b.c0, c.c0), F::template sub3<K>(a.c1, b.c1, c.c1)};
   }
   // Karatsuba on unreduced columns (3 limb products, 2 reductions) was tried: the six live operands plus two sets
   // of Montgomery quotients spill the accumulate kernel to scratch (G2 accumulate 8.7 -> 126 ms); two sums of
@@ -446,6 +571,24 @@ template <class F, int B> CTT_HD F fsub(const F& a, const F& b) {
 template <class F, int B> CTT_HD F fcneg(const F& a, bool c) {
   if constexpr (F::UNSAT) return F::template cneg<B>(a, c); else return F::cneg(a, c);
 }
+// lazy operands (fpu.h "lazy forms"): which products of field F may take them
+template <class F> struct LazyOps { static constexpr bool ONE = false, BOTH = false; };
+template <class UP> struct LazyOps<FpU<UP>> { static constexpr bool ONE = FpU<UP>::LAZY_ONE, BOTH = FpU<UP>::LAZY_BOTH; };
+// a - b + (B+1)*p, lazy when LZ (the caller names the product rule it relies on) -- else the normalised a - b + B*p.
+// Either way the value is < bound(a) + B + 1.
+template <class F, int B, bool LZ> CTT_HD F fsub_lz(const F& a, const F& b) {
+  if constexpr (LZ) return F::template sub_lazy<B>(a, b); else return fsub<F, B>(a, b);
+}
+template <class F, int B, bool LZ> CTT_HD F fcneg_lz(const F& a, bool c) {
+  if constexpr (LZ) return F::template cneg_lazy<B>(a, c); else return fcneg<F, B>(a, c);
+}
+template <class F, bool LZ> CTT_HD F fnorm(const F& a) {
+  if constexpr (LZ) return F::norm(a); else return a;
+}
+// a - b - 2c (+ K*p), normalised: b + 2c < (K-1)*p
+template <class F, int K> CTT_HD F fsub3(const F& a, const F& b, const F& c) {
+  if constexpr (F::UNSAT) return F::template sub3<K>(a, b, c); else return F::sub(F::sub(a, b), F::dbl(c));
+}
 // a*b - c*d with one reduction where the field supports it; B bounds d's partner c (c < B*p)
 template <class F> struct IsFp2 { static constexpr bool value = false; };
 template <class B> struct IsFp2<Fp2<B>> { static constexpr bool value = true; };
@@ -458,6 +601,10 @@ template <class F, int B> CTT_HD F fmul_sub(const F& a, const F& b, const F& c, 
   } else {
     return F::sub(F::mul(a, b), F::mul(c, d));
   }
+}
+// a*b - c*d (c < B*p) with c's negation lazy when LZ
+template <class F, int B, bool LZ> CTT_HD F fmul_sub_lz(const F& a, const F& b, const F& c, const F& d) {
+  if constexpr (LZ) return F::mul2(a, b, F::template sub_lazy<B>(F::zero(), c), d); else return fmul_sub<F, B>(a, b, c, d);
 }
 // two independent products / squares: interleaved where the field supports it (fpu.h mul_pair)
 template <class F> CTT_HD void fmul_pair(const F& a, const F& b, const F& c, const F& d, F& r1, F& r2) {

@@ -185,34 +185,12 @@ __global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t
   gen_point_body<typename C::F>(G, seed, first, n, out, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// probe of the device field FD: inputs in the reference representation, output = raw FD limbs
-// (op 0 mul, 1 sqr, 2 add, 3 sub<2>, 4 conversion only)
+// probe of the device field FD (msm_bodies.h dev_field_probe): inputs in the reference representation, output = raw FD limbs
 template <class F, class FD>
 __global__ void k_field_op_dev(int op, const F* a, const F* b, FD* r, uint32_t n) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  if constexpr (FD::UNSAT) {
-    FD x = FD::from_sat(a[j]), y = FD::from_sat(b[j]), o;
-    switch (op) {
-      case 0: o = FD::mul(x, y); break;
-      case 1: o = FD::sqr(x); break;
-      case 2: o = FD::add(x, y); break;
-      case 3: o = FD::template sub<2>(x, y); break;
-      // operands at the largest bounds the curve arithmetic feeds into a product (ec.h: 5M and 3M, M = 2)
-      case 5: {
-        constexpr int BA = FD::HEADROOM_LOG2 >= 7 ? 9 : 5, BB = FD::HEADROOM_LOG2 >= 7 ? 9 : 4;
-        o = FD::mul(FD::template sub<BA>(x, FD::zero()), FD::template sub<BB>(y, FD::zero()));
-        break;
-      }
-      case 6: {
-        constexpr int BA = FD::HEADROOM_LOG2 >= 7 ? 9 : 5;
-        o = FD::sqr(FD::template sub<BA>(x, FD::zero()));
-        break;
-      }
-      default: o = x; break;
-    }
-    r[j] = o;
-  }
+  if constexpr (FD::UNSAT) r[j] = dev_field_probe<FD>(op, FD::from_sat(a[j]), FD::from_sat(b[j]));
 }
 
 // field-op probe for the GPU unit tests: op 0 mul, 1 sqr, 2 add, 3 sub, 4 neg
@@ -405,13 +383,11 @@ struct CurveOps {
   size_t aff_bytes;
   void* (*engine_create)(HipBackend* bk);
   void (*engine_destroy)(void* eng);
-  // runs one MSM on device-resident inputs, writes r (host) in out_kind coordinates, fills plan[6]
-  void (*run)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
-              void* r_host, int out_kind, int* plan);
-  // split form: at most two MSMs in flight per engine; submit returns the slot (0/1)
+  // split form: at most two MSMs in flight per engine; submit returns the slot (0/1), or -1 when both are taken;
+  // finish returns 0, or -1 when the slot is not in flight
   int (*submit)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
                 int* plan);
-  void (*finish)(void* eng, int slot, void* r_host, int out_kind);
+  int (*finish)(void* eng, int slot, void* r_host, int out_kind);
   // cached bases: device records for `n` points (d_points in the C-API layout, device memory); submit against them
   void* (*bases_prepare)(void* eng, const void* d_points, uint32_t n);
   int (*submit_bases)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_prepared,
@@ -439,18 +415,6 @@ struct CurveImpl {
     return e;
   }
   static void destroy(void* e) { delete (Engine*)e; }
-  static void run(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
-                  void* r_host, int out_kind, int* plan) {
-    Engine& e = *(Engine*)eng;
-    uint32_t lanes = e.opt.lanes;
-    e.opt = *opt;
-    e.opt.lanes = lanes;
-    auto res = e.run((const uint32_t*)d_coefs, coef_is_fr != 0, (const Affine<F>*)d_points, n);
-    const MsmPlan& p = e.last_plan;
-    plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
-    plan[6] = e.next_slot ^ 1;  // slot this MSM used
-    write_result<typename Engine::HF>(r_host, res, out_kind);
-  }
   static int submit(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
                     int* plan) {
     Engine& e = *(Engine*)eng;
@@ -458,6 +422,7 @@ struct CurveImpl {
     e.opt = *opt;
     e.opt.lanes = lanes;
     int sl = e.submit((const uint32_t*)d_coefs, coef_is_fr != 0, (const Affine<F>*)d_points, n);
+    if (sl < 0) return sl;
     const MsmPlan& p = e.last_plan;
     plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
     return sl;
@@ -472,14 +437,17 @@ struct CurveImpl {
     e.opt = *opt;
     e.opt.lanes = lanes;
     int sl = e.submit((const uint32_t*)d_coefs, coef_is_fr != 0, nullptr, n, d_prepared);
+    if (sl < 0) return sl;
     const MsmPlan& p = e.last_plan;
     plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
     return sl;
   }
-  static void finish(void* eng, int slot, void* r_host, int out_kind) {
+  static int finish(void* eng, int slot, void* r_host, int out_kind) {
     Engine& e = *(Engine*)eng;
+    if (!e.in_flight(slot)) return -1;
     auto res = e.finish(slot);
     write_result<typename Engine::HF>(r_host, res, out_kind);
+    return 0;
   }
   static void gen_points(HipBackend* bk, uint64_t seed, uint64_t first, uint32_t n, void* d_out) {
     hipLaunchKernelGGL(k_gen_points<C>, dim3((n + EC_BLOCK - 1) / EC_BLOCK), dim3(EC_BLOCK), 0, bk->stream, seed, first, n,
@@ -524,7 +492,7 @@ struct CurveImpl {
     HIP_CHECK(hipGetLastError());
   }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, run, submit, finish, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F)};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F)};
     return &o;
   }
 };

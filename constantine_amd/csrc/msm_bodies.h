@@ -450,6 +450,29 @@ CTT_HD void batch_affine_body(const BatchAffineArgs<F>& a, uint32_t lane) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Probe of the device field FD for the unit tests (GPU: k_field_op_dev, CPU: tests/emu), operands x, y < 2p:
+//   0 mul   1 sqr   2 add   3 sub<2>   4 conversion only
+//   5, 6, 7  products with operands at the largest bounds -- and in the lazy forms -- that xyzz_madd feeds them
+//            (ec.h): 5 = x*y as (x + 10p)(y + 10p) resp. (x + 4p)(y + 10p), 6 = x^2 as (x + 10p)^2 resp. (x + 9p)^2,
+//            7 = x*y - x*x as the sum of products R*T + (5p - x)*x of Y3
+// ---------------------------------------------------------------------------------------------
+template <class FD>
+CTT_HD FD dev_field_probe(int op, const FD& x, const FD& y) {
+  constexpr bool L1 = LazyOps<FD>::ONE, L2 = LazyOps<FD>::BOTH;
+  const FD z = FD::zero();
+  switch (op) {
+    case 0: return FD::mul(x, y);
+    case 1: return FD::sqr(x);
+    case 2: return FD::add(x, y);
+    case 3: return FD::template sub<2>(x, y);
+    case 5: return FD::mul(fsub_lz<FD, (L2 ? 9 : 4), L2>(x, z), fsub_lz<FD, 9, L1>(y, z));
+    case 6: return FD::sqr(fsub_lz<FD, 9, L2>(x, z));
+    case 7: return fmul_sub_lz<FD, 4, L1>(fsub_lz<FD, 4, L2>(x, z), fsub_lz<FD, 9, L1>(y, z), x, x);
+    default: return x;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic subgroup points for benchmarks/tests: P_i = [s_i]G, s_i = 128-bit splitmix word pair | 1
 // (same definition as oracle/pyoracle.py synth_point; mirrors the distribution of the reference's
 // bench inputs, benchmarks/bench_elliptic_parallel_template.nim:78-102)

@@ -214,14 +214,12 @@ struct MsmEngine {
   }
 
   // d_prepared (optional): records made by prepare_bases for the same points; skips the per-MSM conversion.
+  // Returns the slot, or -1 when both slots are in flight.
   int submit(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n,
              const void* d_prepared = nullptr) {
     const int sl = next_slot;
     Slot& S = slots[sl];
-    if (S.busy) {
-      fprintf(stderr, "[ctt_msm] FATAL: more than two MSMs in flight on one engine (finish() the oldest first)\n");
-      abort();
-    }
+    if (S.busy) return -1;  // two MSMs in flight already: the caller finishes the oldest first (C ABI: error code)
     next_slot ^= 1;
     S.busy = true;
     S.empty = (n == 0);  // len == 0 is UB upstream; we return the neutral
@@ -277,6 +275,11 @@ struct MsmEngine {
     bk.fetch_u32_async(d_maxcount);  // largest bucket: read back while the accumulation runs
     bk.stage_end(sl, ST_SORT);
 
+    // The previous MSM's tail (narrow reduction passes + result copy on the backend's second stream) has had this MSM's
+    // conversion and sort to run underneath; the accumulation must not start before it is done: k_accum takes every
+    // wave slot of the chip for its whole duration, and a tail kernel enqueued behind it would wait it out (measured on
+    // a slower box: reduce span 2.4 ms, the pipeline slower than the serial order).  Worst case this is the serial order.
+    bk.tail_wait();
     bk.stage_begin(sl, ST_ACCUM);
     XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(buckets, (size_t)W * B * sizeof(XYZZ<FD>));
     bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
@@ -307,9 +310,8 @@ struct MsmEngine {
     XYZZ<FD>* d_q = (XYZZ<FD>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<FD>));
     XYZZ<FD>* d_out = (XYZZ<FD>*)need(rP[0], (size_t)W * p.c * sizeof(XYZZ<FD>));
     // The narrow passes at the end (and the result copy) move to the backend's tail stream: they are latency-bound
-    // and the next MSM's conversion and sort fit underneath them.  tail_wait() orders the previous MSM's tail before
-    // this MSM's first write to the pyramid buffers.
-    bk.tail_wait();
+    // and the next MSM's conversion and sort fit underneath them (the tail_wait() before the accumulation also orders
+    // the previous tail before this MSM's first write to the pyramid buffers).
     bool forked = false;
     for (int pass = 0; pass <= p.c - 2; pass++) {
       PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass};
@@ -352,9 +354,7 @@ struct MsmEngine {
     return combine_windows_bits<HF>(sums.data(), p.W, p.c);
   }
 
-  XYZZ<HF> run(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n) {
-    return finish(submit(d_coefs, coef_is_fr, d_points_in, n));
-  }
+  bool in_flight(int sl) const { return sl >= 0 && sl < 2 && slots[sl].busy; }
 
   // r = sum of n affine points (sum_reduce_vartime, ec_shortweierstrass_batch_ops.nim:649-663).  One window, one
   // bucket: the identity entry list goes through the accumulate kernel (K points per lane) and the head-merging
@@ -362,6 +362,7 @@ struct MsmEngine {
   uint32_t last_sum_K = 0;
   XYZZ<HF> sum_reduce(const Affine<F>* d_points_in, uint32_t n) {
     if (n == 0) return XYZZ<HF>::inf();
+    bk.tail_wait();  // shares the workspace with MSMs in flight
     const uint32_t lanes = opt.lanes ? opt.lanes : 65536;
     uint32_t K = (uint32_t)(((uint64_t)n + lanes - 1) / lanes);
     if (K < 16) K = 16;

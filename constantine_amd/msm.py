@@ -87,10 +87,27 @@ class DeviceMsm:
     def _dptr(t):
         return ctypes.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
 
+    def _order(self, *tensors):
+        """Order the engine's stream after torch's current stream when an argument is a torch CUDA tensor: the engine
+        runs on its own non-blocking streams, so without this a kernel that is still producing the tensor could be
+        overtaken (ctt_hip_msm_wait_stream; INTEGRATION.md "Stream ordering").  Raw integer addresses carry no stream:
+        their owner orders them (wait_stream / a synchronize)."""
+        for t in tensors:
+            if hasattr(t, "data_ptr") and getattr(t, "is_cuda", False):
+                import torch
+                self.wait_stream(torch.cuda.current_stream(t.device).cuda_stream)
+                return
+
+    def wait_stream(self, stream):
+        """Everything the engine enqueues from now on waits for the work `stream` (a hipStream_t address) holds now."""
+        if self.L.ctt_hip_msm_wait_stream(self.ctx, ctypes.c_void_p(int(stream))) != 0:
+            raise RuntimeError("ctt_hip_msm_wait_stream failed")
+
     def msm(self, curve, d_coefs, d_points, n, coord="aff", fr_coefs=False):
         info = CURVES[curve]
         nco = 2 if coord == "aff" else 3
         r = np.zeros(nco * info.coord_bytes, dtype=np.uint8)
+        self._order(d_coefs, d_points)
         rc = self.L.ctt_hip_msm_device(self.ctx, info.cid, COEF_FR if fr_coefs else COEF_BIG, _COORD[coord], _ptr(r),
                                        self._dptr(d_coefs), self._dptr(d_points), n)
         if rc != 0:
@@ -98,12 +115,13 @@ class DeviceMsm:
         return r
 
     def submit(self, curve, d_coefs, d_points, n, fr_coefs=False):
-        """Enqueue one MSM and return a ticket at once (at most two outstanding per curve)."""
+        """Enqueue one MSM and return a ticket at once (at most two outstanding per curve: a third raises)."""
         info = CURVES[curve]
+        self._order(d_coefs, d_points)
         t = self.L.ctt_hip_msm_device_submit(self.ctx, info.cid, COEF_FR if fr_coefs else COEF_BIG,
                                              self._dptr(d_coefs), self._dptr(d_points), n)
         if t < 0:
-            raise RuntimeError("ctt_hip_msm_device_submit failed")
+            raise RuntimeError("ctt_hip_msm_device_submit failed (bad arguments, or two tickets already outstanding)")
         return (curve, t)
 
     def finish(self, ticket, coord="aff"):
@@ -113,7 +131,7 @@ class DeviceMsm:
         nco = 2 if coord == "aff" else 3
         r = np.zeros(nco * info.coord_bytes, dtype=np.uint8)
         if self.L.ctt_hip_msm_device_finish(self.ctx, t, _COORD[coord], _ptr(r)) != 0:
-            raise RuntimeError("ctt_hip_msm_device_finish failed")
+            raise RuntimeError("ctt_hip_msm_device_finish failed (ticket not outstanding)")
         return r
 
     def sync(self):
@@ -121,11 +139,13 @@ class DeviceMsm:
         self.L.ctt_hip_msm_sync(self.ctx)
 
     def gen_points(self, curve, seed, n, d_out, first=0):
+        self._order(d_out)
         rc = self.L.ctt_hip_gen_points(self.ctx, CURVES[curve].cid, seed & (2**64 - 1), first, n, self._dptr(d_out))
         if rc != 0:
             raise RuntimeError("ctt_hip_gen_points failed")
 
     def field_op(self, curve, op, d_a, d_b, d_r, n):
+        self._order(d_a, d_b, d_r)
         rc = self.L.ctt_hip_field_op(self.ctx, CURVES[curve].cid, op, self._dptr(d_a), self._dptr(d_b), self._dptr(d_r), n)
         if rc != 0:
             raise RuntimeError("ctt_hip_field_op failed")
@@ -135,12 +155,14 @@ class DeviceMsm:
         info = CURVES[curve]
         nco = 2 if coord == "aff" else 3
         r = np.zeros(nco * info.coord_bytes, dtype=np.uint8)
+        self._order(d_points)
         if self.L.ctt_hip_sum_reduce(self.ctx, info.cid, _COORD[coord], _ptr(r), self._dptr(d_points), n, 1) != 0:
             raise RuntimeError("ctt_hip_sum_reduce failed")
         return r
 
     def batch_affine(self, curve, d_dst, d_src, n, src_coord="jac"):
-        """d_dst[i] = affine(d_src[i]); both in HBM (batchAffine_vartime)."""
+        """d_dst[i] = affine(d_src[i]); both in HBM (batchAffine_vartime).  Returns when d_dst is complete."""
+        self._order(d_src, d_dst)
         if self.L.ctt_hip_batch_affine(self.ctx, CURVES[curve].cid, _COORD[src_coord], self._dptr(d_dst),
                                        self._dptr(d_src), n, 1) != 0:
             raise RuntimeError("ctt_hip_batch_affine failed")
@@ -154,6 +176,19 @@ class DeviceMsm:
         p = np.zeros(6, dtype=np.int32)
         self.L.ctt_hip_msm_last_plan(self.ctx, _ptr(p), 6)
         return dict(zip(("c", "W", "K", "G", "S", "lanes"), (int(x) for x in p)))
+
+
+def set_devices(devices):
+    """GPUs the host-pointer entry points (multiScalarMul_vartime[_parallel], CttEngine.msm) shard a call over, by points
+    (ctt_hip_msm_set_devices; the reference's msm-level split, ec_multi_scalar_mul_parallel.nim:386-431).  A device id may
+    repeat (one context each); fewer than two ids turns sharding off."""
+    arr = (ctypes.c_int * max(1, len(devices)))(*devices)
+    if _lib.lib().ctt_hip_msm_set_devices(arr, len(devices)) != 0:
+        raise ValueError(f"device id out of range in {list(devices)}")
+
+
+def set_shard_min(pairs_per_device):
+    _lib.lib().ctt_hip_msm_set_shard_min(int(pairs_per_device))
 
 
 def ec_sum_affine(curve, pts_aff, coord="aff"):
@@ -199,7 +234,9 @@ class CachedBases:
         self.info = CURVES[curve]
         self.ctx = ctx
         if on_device:
+            import torch
             self.n = int(points.shape[0])
+            torch.cuda.current_stream(points.device).synchronize()  # the records are made from the tensor as it is now
             ptr = ctypes.c_void_p(points.data_ptr())
         else:
             points = np.ascontiguousarray(points, dtype=np.uint8)

@@ -138,32 +138,45 @@ enum { CTT_HIP_COEF_BIG = 0, CTT_HIP_COEF_FR = 1 };
 enum { CTT_HIP_OUT_AFF = 0, CTT_HIP_OUT_JAC = 1, CTT_HIP_OUT_PRJ = 2 };
 
 int ctt_hip_msm_abi_version(void);
-/* One context = one GPU, one stream, one grow-only workspace. NULL ctx in the calls below = process default
+/* One context = one GPU, its streams, one grow-only workspace. NULL ctx in the calls below = process default
  * context on device $CTT_HIP_DEVICE (default 0). */
 ctt_hip_msm_ctx* ctt_hip_msm_ctx_create(int device);
 void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
-/* key in {"c","K","S","lanes"}: window bits, sorted entries per accumulate lane, scalars per sort-partition workgroup;
- * value 0 = automatic ("lanes": 1 or 2 streams for submit). Returns 0, or -1 for an unknown key. */
+/* key in {"c","K","S"}: window bits, sorted entries per accumulate lane, scalars per sort-partition workgroup;
+ * value 0 = automatic. Returns 0, or -1 for an unknown key. */
 int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
 /* r (HOST memory, `out_kind` layout) = sum coefs[i] * points[i]; d_coefs / d_points are DEVICE pointers
  * (BigInt canonical or Fr Montgomery 32-byte scalars; affine Montgomery points, C-API struct layout).
- * Returns 0, or -1 for a bad curve id.  Blocks until r is written. */
+ * Returns 0; -1 for a bad curve id, len > 2^31-1, or two tickets outstanding on the curve.  Blocks until r is written. */
 int ctt_hip_msm_device(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, int out_kind, void* r, const void* d_coefs,
                        const void* d_points, size_t len);
-/* Split form: submit enqueues the GPU work of one MSM and returns a ticket (>= 0, or -1 on bad arguments) at once;
- * finish waits for it, runs the host tail (Horner over windows, affine normalisation) and writes r.  At most two
- * tickets per curve may be outstanding; submitting MSM i+1 before finishing MSM i overlaps the host tail of i with
- * the GPU work of i+1 (this is how bench.py keeps the GPU busy between steps). */
+/* Split form: submit enqueues the GPU work of one MSM and returns a ticket (>= 0) at once, or -1 on bad arguments or
+ * when two tickets are outstanding on the curve; finish waits for the ticket, runs the host tail (Horner over windows,
+ * affine normalisation) and writes r (0, or -1 for a ticket that is not outstanding).  Submitting MSM i+1 before
+ * finishing MSM i overlaps the host tail of i with the GPU work of i+1 (how bench.py keeps the GPU busy). */
 int ctt_hip_msm_device_submit(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, const void* d_coefs, const void* d_points,
                               size_t len);
 int ctt_hip_msm_device_finish(ctt_hip_msm_ctx* ctx, int ticket, int out_kind, void* r);
-/* Wait for everything enqueued on the context's stream(s) (successive submits alternate between two streams so
- * that the latency-bound tail of one MSM overlaps the next MSM's sort and accumulation). */
+/* Wait for everything enqueued on the context's streams (the main one and the tail stream that carries the last,
+ * latency-bound reduction passes of an MSM underneath the next MSM's conversion and sort). */
 void ctt_hip_msm_sync(ctt_hip_msm_ctx* ctx);
+/* Stream ordering: the engine's streams are not ordered against the caller's.  When device inputs may still be in
+ * flight on `producer` (a hipStream_t), call this first: what the engine enqueues afterwards waits for the work
+ * `producer` holds now.  Device outputs (ctt_hip_batch_affine on device arrays) are complete when their call returns. */
+int ctt_hip_msm_wait_stream(ctt_hip_msm_ctx* ctx, void* producer);
+/* Multi-GPU: the host-pointer symbols of Part 1 shard a call by points over these devices -- the reference's msm-level
+ * split (ec_multi_scalar_mul_parallel.nim:386-431; balanced chunks, threadpool/partitioners.nim:44-77) with GPUs for
+ * threads: each slice is uploaded to its own GPU and the partial results are summed on the host.  `n` device ids (an
+ * id may repeat: one context each); n < 2 turns sharding off.  Default: $CTT_HIP_DEVICES ("0,1,2,3" or "all"), else
+ * off.  Calls below shard_min pairs per device (default 2^15, $CTT_HIP_SHARD_MIN) use fewer devices.
+ * Returns 0, or -1 for a device id out of range. */
+int ctt_hip_msm_set_devices(const int* devices, int n);
+void ctt_hip_msm_set_shard_min(size_t pairs_per_device);
 /* Cached bases -- the Halo2-ZAL descriptor hooks (constantine-halo2-zal/src/lib.rs:60-95: get_base_descriptor,
  * msm_with_cached_base): base points are uploaded and converted to the device representation once and stay resident
  * in HBM; later MSMs move only the 32-byte coefficients. `points` / `coefs` are host pointers when the
- * *_on_device flag is 0, device pointers when it is 1. ctt_hip_msm_with_bases uses the first `len` bases. */
+ * *_on_device flag is 0, device pointers when it is 1. ctt_hip_msm_with_bases uses the first `len` bases and must be
+ * called with the context the bases were created on (-1 otherwise: the records live on that context's GPU). */
 typedef struct ctt_hip_msm_bases ctt_hip_msm_bases;
 ctt_hip_msm_bases* ctt_hip_msm_bases_create(ctt_hip_msm_ctx* ctx, int curve, const void* points, size_t len,
                                             int points_on_device);

@@ -16,10 +16,26 @@ def build():
     subprocess.check_call(["make", "-s", "-C", HERE, "libmsm_ref.so"])
 
 
-def lib():
+def build_native():
+    """Rebuild the same source for the CPU this process runs on (g++ -march=native) and switch to that build: the shipped
+    libmsm_ref.so targets x86-64-v3 so that it runs on any box.  Returns the flags of the build now in use."""
+    global _lib
+    path = os.path.join(HERE, "libmsm_ref_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", HERE, "libmsm_ref_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib = None
+        lib(path)
+        return "g++ -O3 -march=native (built on this host)"
+    except Exception:
+        _lib = None
+        lib()
+        return "g++ -O3 -march=x86-64-v3 (shipped build; native rebuild failed)"
+
+
+def lib(path=None):
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "libmsm_ref.so")
+        path = path or os.path.join(HERE, "libmsm_ref.so")
         if not os.path.exists(path):
             build()
         L = ctypes.CDLL(path)

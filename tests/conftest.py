@@ -10,9 +10,3 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
-def pytest_collection_modifyitems(config, items):
-    # GPU tests must fail loudly (not skip) on a GPU box, and never run on the CPU-only box
-    # unless explicitly selected with -m gpu.
-    pass

@@ -160,25 +160,7 @@ struct EmuCurve {
   // device-field probe: inputs in the reference representation, output raw FD limbs (uint32[NL]); returns NL
   static int fop_dev(int op, const void* a, const void* b, void* r) {
     if constexpr (FD::UNSAT) {
-      FD x = FD::from_sat(*(const F*)a), y = FD::from_sat(*(const F*)b), o;
-      switch (op) {
-        case 0: o = FD::mul(x, y); break;
-        case 1: o = FD::sqr(x); break;
-        case 2: o = FD::add(x, y); break;
-        case 3: o = FD::template sub<2>(x, y); break;
-        // operands at the largest bounds the curve arithmetic feeds into a product (ec.h: 5M and 3M, M = 2)
-        case 5: {
-          constexpr int BA = FD::HEADROOM_LOG2 >= 7 ? 9 : 5, BB = FD::HEADROOM_LOG2 >= 7 ? 9 : 4;
-          o = FD::mul(FD::template sub<BA>(x, FD::zero()), FD::template sub<BB>(y, FD::zero()));
-          break;
-        }
-        case 6: {
-          constexpr int BA = FD::HEADROOM_LOG2 >= 7 ? 9 : 5;
-          o = FD::sqr(FD::template sub<BA>(x, FD::zero()));
-          break;
-        }
-        default: o = x; break;
-      }
+      FD o = dev_field_probe<FD>(op, FD::from_sat(*(const F*)a), FD::from_sat(*(const F*)b));
       *(FD*)r = o;
       return FD::NL;
     }

@@ -1,6 +1,9 @@
 """world_size-2 gloo test of the point-sharded MSM (constantine_amd/parallel.py) on CPU.
-The per-rank partial MSM is computed by the oracle here (no GPU in this container); the sharding, the
-all_gather exchange and the host-side combine (product code, ctt_hip_ec_sum_affine) are the parts under test."""
+There is no GPU in this container, so every rank's partial MSM is computed by tests/emu -- the CPU emulator that runs the
+engine's own kernel bodies and host orchestration (msm_bodies.h, msm_pipeline.h) -- and the sharding, the all_gather
+exchange and the host-side combine (product code, ctt_hip_ec_sum_affine) run as they do on the GPUs.  The oracle only
+checks the combined result.  The GPU engine itself runs the same two-rank path in tests/test_gpu_parity.py
+(two contexts on one device) and in `bench.py --gpus 2 --all-ranks-on-device 0 --backend gloo`."""
 import os
 import socket
 import sys
@@ -33,7 +36,8 @@ def _worker(rank, world, port, name, n, q):
         start, ln = parallel.shard_bounds(n, world, rank)
         pts = cref.gen_points(name, 77, ln, first=start, nthreads=1)
         sc = cref.synth_scalars(78, ln, bits, first=start)
-        res = parallel.msm_sharded(name, lambda: cref.msm(name, sc, pts)[0])
+        from tests.emu import emu
+        res = parallel.msm_sharded(name, lambda: emu.msm(name, sc, pts, out_kind=0)[0])
         q.put((rank, bytes(res)))
     finally:
         dist.destroy_process_group()

@@ -88,7 +88,8 @@ def test_carry_free_device_field_vs_python(name):
     for _ in range(200 if deg == 1 else 60):
         a, b = rnd(), rnd()
         for op, want, bound in ((0, F.mul(a, b), 2), (1, F.sqr(a), 2), (2, F.add(a, b), 4), (3, F.sub(a, b), 4), (4, a, 2),
-                                 (5, F.mul(a, b), 2), (6, F.sqr(a), 2)):   # 5, 6: operands biased up to the largest bounds ec.h uses
+                                 (5, F.mul(a, b), 2), (6, F.sqr(a), 2), (7, F.sub(F.mul(a, b), F.sqr(a)), 4)):
+            # 5-7: operands at the largest bounds, and in the lazy forms, that ec.h feeds into products
             assert dec(emu.field_op_dev(name, op, enc(a), enc(b)), bound) == want, (name, op, a, b)
     # raw zero in -> raw zero out (neutral flags rely on it)
     z = F.from_int(0)

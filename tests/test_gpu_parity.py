@@ -112,7 +112,8 @@ def test_carry_free_field_on_device(name, dev, torch_cuda):
     da, db = _to_dev(torch, a), _to_dev(torch, b)
     dr = torch.zeros((n, nl * deg), dtype=torch.int32, device="cuda")
     ops = {0: (F.mul, 2), 1: (lambda x, y: F.sqr(x), 2), 2: (F.add, 4), 3: (F.sub, 4), 4: (lambda x, y: x, 2),
-           5: (F.mul, 2), 6: (lambda x, y: F.sqr(x), 2)}   # 5, 6: operands biased up to the largest bounds ec.h feeds into a product
+           5: (F.mul, 2), 6: (lambda x, y: F.sqr(x), 2), 7: (lambda x, y: F.sub(F.mul(x, y), F.sqr(x)), 4)}
+    # 5-7: operands at the largest bounds, and in the lazy forms, that ec.h feeds into products (dev_field_probe)
     for op, (fn, bound) in ops.items():
         dev.field_op(name, 16 + op, da, db, dr, n)
         out = dr.cpu().numpy().astype(np.uint32)
@@ -364,24 +365,26 @@ def test_sort_under_skewed_digit_distributions(dev, torch_cuda):
 
 
 # ----------------------------------------------------------------------------------------------
-# BASELINE.json sizes
+# BASELINE.json sizes: every config is byte-compared with the oracle on its FULL input
 # ----------------------------------------------------------------------------------------------
-def _full_size(name, lg, dev, torch, check_oracle):
+def _full_size(name, lg, dev, torch, seed=None):
+    """Oracle on the whole input (oracle/msm_ref.cpp: ~1.2 M pairs/s on the box's 16 CPUs), then two size-independent
+    properties the reference's tests cannot use: the sum of the half-MSMs, and a different plan giving the same element."""
     from constantine_amd.msm import ec_sum_affine
     curve = po.CURVES[name]
     n = 1 << lg
     info_bytes = cref.AFF_BYTES[name]
     dp = torch.empty((n, info_bytes), dtype=torch.uint8, device="cuda")
-    dev.gen_points(name, 1000 + lg, n, dp)
+    dev.gen_points(name, seed or (1000 + lg), n, dp)
     sc = cref.synth_scalars(2000 + lg, n, curve.scalar_bits)
     ds = _to_dev(torch, sc)
     full = dev.msm(name, ds, dp, n, coord="aff")
-    # size-independent property 1: the sum of the two half-MSMs is the whole MSM
+    expect, _ = cref.msm(name, sc, dp.cpu().numpy(), nthreads=NT)
+    assert bytes(expect) == bytes(full)
     h = n // 2
     a = dev.msm(name, ds[:h], dp[:h], h, coord="aff")
     b = dev.msm(name, ds[h:], dp[h:], n - h, coord="aff")
     assert bytes(ec_sum_affine(name, np.stack([a, b]))) == bytes(full)
-    # property 2: a different plan (window size, lane span) gives the same element
     dev.set_option("c", 13)
     dev.set_option("K", 36)
     try:
@@ -389,19 +392,16 @@ def _full_size(name, lg, dev, torch, check_oracle):
     finally:
         dev.set_option("c", 0)
         dev.set_option("K", 0)
-    if check_oracle:
-        expect, _ = cref.msm(name, sc, dp.cpu().numpy(), nthreads=NT)
-        assert bytes(expect) == bytes(full)
 
 
 def test_bls12_381_g1_2pow20(dev, torch_cuda):
     """BASELINE config 2: BLS12-381 G1, 2^20 pairs, bit-exact vs the CPU path."""
-    _full_size("bls12_381_g1", 20, dev, torch_cuda, check_oracle=True)
+    _full_size("bls12_381_g1", 20, dev, torch_cuda)
 
 
-def test_bls12_381_g1_2pow24_properties(dev, torch_cuda):
-    """BASELINE config 4 size (2^24 pairs) on one GPU: size-independent properties + sharded-sum identity over 8 slices
-    (what the 8-GPU run computes: MSM = sum of the per-rank MSMs over balanced slices)."""
+def test_bls12_381_g1_2pow24_full_oracle(dev, torch_cuda):
+    """BASELINE config 4 (2^24 pairs; 8 GPUs there, one here): the oracle on all 2^24 pairs (~15 s of CPU), and the
+    sharded-sum identity over the 8 balanced slices the 8-GPU run computes (MSM = sum of the per-rank MSMs)."""
     torch = torch_cuda
     from constantine_amd.msm import ec_sum_affine
     from constantine_amd.parallel import shard_bounds
@@ -409,48 +409,52 @@ def test_bls12_381_g1_2pow24_properties(dev, torch_cuda):
     n = 1 << 24
     dp = torch.empty((n, 96), dtype=torch.uint8, device="cuda")
     dev.gen_points(name, 2424, n, dp)
-    ds = _to_dev(torch, cref.synth_scalars(2425, n, 255))
+    sc = cref.synth_scalars(2425, n, 255)
+    ds = _to_dev(torch, sc)
     full = dev.msm(name, ds, dp, n, coord="aff")
     parts = []
     for r in range(8):
         s0, ln = shard_bounds(n, 8, r)
         parts.append(dev.msm(name, ds[s0:s0 + ln], dp[s0:s0 + ln], ln, coord="aff"))
     assert bytes(ec_sum_affine(name, np.stack(parts))) == bytes(full)
-    # oracle on a prefix
-    m = 1 << 18
-    expect, _ = cref.msm(name, ds[:m].cpu().numpy(), dp[:m].cpu().numpy(), nthreads=NT)
-    assert bytes(dev.msm(name, ds[:m], dp[:m], m, coord="aff")) == bytes(expect)
-
-
-def test_bn254_g1_2pow22_properties(dev, torch_cuda):
-    """BASELINE config 3 size (2^22); oracle comparison on the first 2^18 pairs."""
-    torch = torch_cuda
-    name = "bn254_snarks_g1"
-    _full_size(name, 22, dev, torch, check_oracle=False)
-    n = 1 << 18
-    dp = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
-    dev.gen_points(name, 555, n, dp)
-    ks = [po.synth_scalar(556, i, 256) % po.CURVES[name].Fr.p for i in range(2048)]
-    sc = cref.synth_scalars(557, n, 254)
     expect, _ = cref.msm(name, sc, dp.cpu().numpy(), nthreads=NT)
-    assert bytes(dev.msm(name, _to_dev(torch, sc), dp, n, coord="aff")) == bytes(expect)
+    assert bytes(expect) == bytes(full)
 
 
-def test_pasta_and_g2_2pow20_properties(dev, torch_cuda):
-    """BASELINE config 5 sizes: properties at 2^20 (Pallas, Vesta) and 2^18 (BLS12-381 G2), oracle on a prefix."""
-    _full_size("pallas", 20, dev, torch_cuda, check_oracle=False)
-    _full_size("vesta", 20, dev, torch_cuda, check_oracle=False)
-    _full_size("bls12_381_g2", 18, dev, torch_cuda, check_oracle=False)
-
-
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_two_msms_in_flight(dev, torch_cuda, lanes):
-    """submit/finish split: results of pipelined MSMs (different sizes, shared workspace) are independent;
-    lanes = 2 alternates successive submits between two streams/workspaces."""
+def test_bn254_g1_2pow22_zal_entry_full_oracle(dev, torch_cuda):
+    """BASELINE config 3: BN254-Snarks G1, 2^22 pairs THROUGH THE HALO2-ZAL ENTRY
+    (CttEngine.msm -> ctt_bn254_snarks_g1_prj_multi_scalar_mul_fr_coefs_vartime_parallel, lib.rs:42-58): Montgomery Fr
+    coefficients on host pointers, projective result, against the oracle on all 2^22 pairs."""
     torch = torch_cuda
-    dev.set_option("lanes", lanes)
+    from constantine_amd import CttEngine
+    name = "bn254_snarks_g1"
+    curve = po.CURVES[name]
+    n = 1 << 22
+    dp = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    dev.gen_points(name, 2222, n, dp)
+    pts = dp.cpu().numpy()
+    mont = cref.synth_scalars(2223, n, 253)          # any 253-bit pattern is a valid Fr Montgomery residue (r > 2^253)
+    can = cref.fr_from_mont(name, mont)              # the canonical scalars the entry point computes with
+    expect = _aff(curve, cref.msm(name, can, pts, nthreads=NT)[0])
+    assert curve.prj_from_bytes(bytes(CttEngine(0).msm(mont, pts))) == expect
+    # the device-resident path on the same pairs (what bench.py --curve bn254_snarks_g1 --log2n 22 times)
+    assert _aff(curve, dev.msm(name, _to_dev(torch, mont), dp, n, coord="aff", fr_coefs=True)) == expect
+    _full_size(name, 22, dev, torch)
+
+
+def test_pasta_and_g2_2pow20_full_oracle(dev, torch_cuda):
+    """BASELINE config 5: BLS12-381 G2, Pallas and Vesta at 2^20 pairs, each against the oracle on the full input."""
+    _full_size("pallas", 20, dev, torch_cuda)
+    _full_size("vesta", 20, dev, torch_cuda)
+    _full_size("bls12_381_g2", 20, dev, torch_cuda)
+
+
+def test_two_msms_in_flight(dev, torch_cuda):
+    """submit/finish split: results of pipelined MSMs (different sizes, shared workspace, the tail of one running under
+    the first kernels of the next) are independent."""
+    torch = torch_cuda
     name = "bls12_381_g1"
-    sizes = [3000, 70000, 1, 4096, 33333]
+    sizes = [3000, 70000, 1, 4096, 33333, 1 << 17, 5]
     data = []
     for i, n in enumerate(sizes):
         pts = cref.gen_points(name, 700 + i, n)
@@ -461,7 +465,91 @@ def test_two_msms_in_flight(dev, torch_cuda, lanes):
         nxt = dev.submit(name, data[i + 1][1], data[i + 1][2], data[i + 1][0]) if i + 1 < len(data) else None
         assert bytes(dev.finish(pending, coord="aff")) == data[i][3], sizes[i]
         pending = nxt
-    dev.set_option("lanes", 1)
+
+
+def test_api_misuse_returns_error_codes(dev, torch_cuda):
+    """Recoverable misuse of the device-resident interface is an error code (RuntimeError here), not an abort: a third
+    ticket on a curve, finishing a ticket twice, a blocking call while two tickets are outstanding, cached bases used
+    with another context."""
+    torch = torch_cuda
+    from constantine_amd import CachedBases, DeviceMsm
+    name = "pallas"
+    n = 2000
+    pts = cref.gen_points(name, 31, n)
+    sc = cref.synth_scalars(32, n, 255)
+    expect = bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
+    ds, dp = _to_dev(torch, sc), _to_dev(torch, pts)
+    t1 = dev.submit(name, ds, dp, n)
+    t2 = dev.submit(name, ds, dp, n)
+    with pytest.raises(RuntimeError):
+        dev.submit(name, ds, dp, n)              # third ticket
+    with pytest.raises(RuntimeError):
+        dev.msm(name, ds, dp, n)                 # blocking call needs a free slot
+    assert bytes(dev.finish(t1)) == expect
+    with pytest.raises(RuntimeError):
+        dev.finish(t1)                           # finished already
+    assert bytes(dev.finish(t2)) == expect
+    assert bytes(dev.msm(name, ds, dp, n)) == expect
+    with pytest.raises(KeyError):
+        dev.set_option("lanes", 2)               # removed option
+    other = DeviceMsm(0)
+    try:
+        bases = CachedBases(name, pts, ctx=other.ctx)
+        assert bytes(bases.msm(sc, coord="aff")) == expect
+        bases.ctx = dev.ctx                       # wrong context: refused, not a wild pointer
+        with pytest.raises(RuntimeError):
+            bases.msm(sc, coord="aff")
+        bases.ctx = other.ctx
+        bases.close()
+    finally:
+        other.close()
+
+
+def test_engine_stream_is_ordered_after_torch(dev, torch_cuda):
+    """Inputs produced by torch kernels that may still be running when the engine is called: the Python
+    mirror orders the engine's stream after torch's current stream (ctt_hip_msm_wait_stream)."""
+    torch = torch_cuda
+    name = "bn254_snarks_g1"
+    n = 1 << 16
+    pts = cref.gen_points(name, 41, n)
+    sc = cref.synth_scalars(42, n, 254)
+    expect = bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
+    junk = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+    good = _to_dev(torch, sc)
+    dp = _to_dev(torch, pts)
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        ds = junk.clone()
+        for _ in range(4):
+            big.add_(1)          # keep torch's stream busy in front of the copy that makes the real input
+        ds.copy_(good)
+        assert bytes(dev.msm(name, ds, dp, n)) == expect
+
+
+def test_host_symbols_shard_over_contexts():
+    """In-library multi-GPU path on this single-GPU box: two (three) contexts on device 0, the Constantine symbols cut the
+    call into balanced slices (partitioners.nim:44-77), one host thread per context, host sum of the partials -- against
+    the oracle on the whole input."""
+    from constantine_amd import multiScalarMul_vartime, multiScalarMul_vartime_parallel, set_devices, set_shard_min
+    try:
+        set_shard_min(1000)
+        for devices, name, n in (([0, 0], "bls12_381_g1", 70001), ([0, 0, 0], "bn254_snarks_g1", 50000),
+                                 ([0, 0], "bls12_381_g2", 5000), ([0, 0], "pallas", 1500)):   # 1500 < 2 x shard_min: one GPU
+            set_devices(devices)
+            curve = po.CURVES[name]
+            pts = cref.gen_points(name, 900 + n, n)
+            sc = cref.synth_scalars(901 + n, n, curve.scalar_bits)
+            expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
+            assert _decode(curve, "jac", multiScalarMul_vartime(name, sc, pts, coord="jac")) == expect
+            if name != "bls12_381_g2":   # the fr_coefs / projective / parallel symbol (the ZAL entry's shape) on a shorter input
+                m = 4000 if n >= 4000 else n
+                mont = cref.synth_scalars(902 + n, m, 253)     # < 2^253 < r: valid Montgomery residues
+                exp2 = _aff(curve, cref.msm(name, cref.fr_from_mont(name, mont), pts[:m], nthreads=NT)[0])
+                got = multiScalarMul_vartime_parallel(None, name, mont, pts[:m], coord="prj", fr_coefs=True)
+                assert _decode(curve, "prj", got) == exp2
+    finally:
+        set_devices([])
+        set_shard_min(1 << 15)
 
 
 @pytest.mark.parametrize("name", ["bls12_381_g1", "pallas", "bls12_381_g2", "bn254_snarks_g2"])
