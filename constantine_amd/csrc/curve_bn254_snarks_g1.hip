@@ -1,3 +1,8 @@
 // curve_bn254_snarks_g1.hip -- instantiates the MSM kernels and engine for Bn254G1 (one TU per curve keeps builds parallel).
+// multiply-add chain form of the device field (fpu.h CTT_FPU_CHAIN), measured per curve (profiles/bench_r02_chain_variants.txt):
+// 4.83 ms (4) vs 4.95 (8) vs 5.13 (0) at 2^22
+#ifndef CTT_FPU_CHAIN
+#define CTT_FPU_CHAIN 4
+#endif  // CTT_FPU_CHAIN
 #include "hip_backend.h"
 extern "C" const ctt::CurveOps* ctt_ops_bn254_snarks_g1(void) { return ctt::CurveImpl<ctt::Bn254G1>::ops(); }

@@ -1,3 +1,8 @@
 // curve_pallas.hip -- instantiates the MSM kernels and engine for PallasEc (one TU per curve keeps builds parallel).
+// multiply-add chain form of the device field (fpu.h CTT_FPU_CHAIN), measured per curve (profiles/bench_r02_chain_variants.txt):
+// 1.058 ms (8) vs 1.068 (4) vs 1.128 (0) at 2^20
+#ifndef CTT_FPU_CHAIN
+#define CTT_FPU_CHAIN 8
+#endif  // CTT_FPU_CHAIN
 #include "hip_backend.h"
 extern "C" const ctt::CurveOps* ctt_ops_pallas(void) { return ctt::CurveImpl<ctt::PallasEc>::ops(); }

@@ -1,3 +1,8 @@
 // curve_vesta.hip -- instantiates the MSM kernels and engine for VestaEc (one TU per curve keeps builds parallel).
+// multiply-add chain form of the device field (fpu.h CTT_FPU_CHAIN), measured per curve (profiles/bench_r02_chain_variants.txt):
+// as Pallas
+#ifndef CTT_FPU_CHAIN
+#define CTT_FPU_CHAIN 8
+#endif  // CTT_FPU_CHAIN
 #include "hip_backend.h"
 extern "C" const ctt::CurveOps* ctt_ops_vesta(void) { return ctt::CurveImpl<ctt::VestaEc>::ops(); }

@@ -85,26 +85,29 @@ CTT_HD XYZZ<F> xyzz_madd_same_x(const F& qx, const F& qy, bool same_y) {
 // Values that only feed products are left lazy (fpu.h "lazy forms") where the field's column budget allows it:
 // L1 = a lazy operand against a normalised one, L2 = lazy against lazy (28-bit limbs only).
 static constexpr int XYZZ_XB = 9;  // stored X < 9p (xyzz_madd's X3 = RR - PPP - 2Q + 7p); the other formulas give < 8p
+// `empty` carries "acc is the neutral element" in a flag instead of acc.zz == 0 (the accumulate kernel's form: no
+// 14-limb zero test per addition and no zero-fill when a bucket is flushed); when it is set acc's limbs are unspecified.
 template <class F>
-CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
+CTT_HD void xyzz_madd_flag(XYZZ<F>& acc, bool& empty, const F& qx, const F& qy_in, bool neg) {
   constexpr int M = F::MULB;                                  // a product is < M*p, M = 2
   constexpr bool L1 = LazyOps<F>::ONE, L2 = LazyOps<F>::BOTH;
   constexpr int XB = XYZZ_XB;
-  if (q.is_inf()) return;
-  F qy = fcneg_lz<F, M, L1>(q.y, neg);                        // < 3, lazy: feeds S2 only (and the rare paths)
-  if (acc.is_inf()) {
-    acc.x = q.x;
-    acc.y = fcneg<F, M>(q.y, neg);                            // normalised, < 2
+  if (empty) {
+    acc.x = qx;
+    acc.y = fcneg<F, M>(qy_in, neg);                          // normalised, < 2
     acc.zz = F::one();
     acc.zzz = F::one();
+    empty = false;
     return;
   }
+  F qy = fcneg_lz<F, M, L1>(qy_in, neg);                      // < 3, lazy: feeds S2 only
   F U2, S2;
-  fmul_pair<F>(q.x, acc.zz, qy, acc.zzz, U2, S2);             // 2*2, 3*2
+  fmul_pair<F>(qx, acc.zz, qy, acc.zzz, U2, S2);              // 2*2, 3*2
   F P = fsub_lz<F, XB, L2>(U2, acc.x);                        // < 2 + 10 = 12; feeds P^2, P*PP
   F R = fsub_lz<F, 2 * M, L2>(S2, acc.y);                     // < 2 + 5 = 7;   feeds R^2, R*T
   if (fis_zero_modp<F, M + XB + 1>(P)) {                      // P == +-Q: rare, out of line
-    acc = xyzz_madd_same_x<F>(q.x, fcneg<F, M>(q.y, neg), fis_zero_modp<F, 3 * M + 1>(R));
+    acc = xyzz_madd_same_x<F>(qx, fcneg<F, M>(qy_in, neg), fis_zero_modp<F, 3 * M + 1>(R));
+    empty = acc.is_inf();
     return;
   }
   F PP, RR, PPP, Q;
@@ -119,6 +122,14 @@ CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
   fmul_pair<F>(acc.zz, PP, acc.zzz, PPP, Z2, Z3);
   acc.zz = Z2;
   acc.zzz = Z3;
+}
+
+template <class F>
+CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
+  if (q.is_inf()) return;
+  bool empty = acc.is_inf();
+  xyzz_madd_flag<F>(acc, empty, q.x, q.y, neg);
+  if (empty) acc = XYZZ<F>::inf();
 }
 
 // acc += q, both XYZZ; returns by value so that neither operand has its address taken

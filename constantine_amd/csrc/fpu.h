@@ -58,8 +58,14 @@ struct FpU {
   }
   CTT_HD static FpU select(bool c, const FpU& a, const FpU& b) {
     FpU r;
+#if defined(CTT_FPU_SELECT_BFI)
+    const uint32_t m = 0u - (uint32_t)c;   // v_bfi_b32 instead of v_cndmask_b32 (experiment)
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = (a.l[i] & m) | (b.l[i] & ~m);
+#else
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+#endif
     return r;
   }
 

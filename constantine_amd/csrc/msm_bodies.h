@@ -102,10 +102,14 @@ CTT_HD void fr_from_mont_body(const uint32_t* in, uint32_t* out, uint32_t n, uin
 
 // Converted points are stored one per 128-byte line: after the sort every lane gathers whole points by index,
 // and a 112-byte (or 72-byte) record at its natural stride would straddle two cache lines most of the time.
+// The last word of the record's padding is a flag: 1 = the affine neutral (0,0) -- the accumulate kernel tests one word
+// instead of all the limbs of x and y.
 template <class FD>
 constexpr uint32_t gather_stride() {
-  return sizeof(Affine<FD>) <= 128 ? 128u : sizeof(Affine<FD>) <= 256 ? 256u : 512u;
+  return sizeof(Affine<FD>) + 4 <= 128 ? 128u : sizeof(Affine<FD>) + 4 <= 256 ? 256u : 512u;
 }
+template <class FD>
+constexpr uint32_t gather_flag_offset() { return gather_stride<FD>() - 4u; }
 
 // Input points: reference representation -> device field (one pass per MSM; (0,0) stays (0,0))
 template <class F, class FD>
@@ -115,7 +119,9 @@ CTT_HD void convert_point_body(const Affine<F>* in, void* out, uint32_t n, uint3
   Affine<FD> q;
   q.x = FD::from_sat(p.x);
   q.y = FD::from_sat(p.y);
-  *(Affine<FD>*)((char*)out + (uint64_t)j * gather_stride<FD>()) = q;
+  char* rec = (char*)out + (uint64_t)j * gather_stride<FD>();
+  *(Affine<FD>*)rec = q;
+  *(uint32_t*)(rec + gather_flag_offset<FD>()) = p.is_inf() ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -159,11 +165,14 @@ CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
   uint32_t b = lo;
   uint32_t bend = bs[b + 1];
   bool first_run = true;
-  XYZZ<F> acc = XYZZ<F>::inf();
+  // the accumulator's "neutral" state lives in a flag (xyzz_madd_flag): nothing to zero when a run is flushed
+  XYZZ<F> acc;
+  bool empty = true;
   const uint32_t* ent = a.entries + (uint64_t)w * a.N;
   for (uint32_t pos = p0; pos < p1; pos++) {
     if (pos == bend) {
       // bucket b is finished inside this lane's range
+      if (empty) acc = XYZZ<F>::inf();
       if (first_run && bs[b] < p0) {
         a.heads[slot] = acc;
         hk = b;
@@ -171,17 +180,19 @@ CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
         a.buckets[(uint64_t)w * a.B + b] = acc;
       }
       first_run = false;
-      acc = XYZZ<F>::inf();
+      empty = true;
       b++;
       while (bs[b + 1] == pos) b++;  // skip empty buckets; terminates because pos < nw
       bend = bs[b + 1];
     }
     uint32_t e = ent[pos];
-    const Affine<F>* pp = (const Affine<F>*)__builtin_assume_aligned(
-        (const char*)a.points + (uint64_t)(e & 0x7fffffffu) * a.point_stride, 16);
-    Affine<F> pt = *pp;
-    xyzz_madd<F>(acc, pt, (e >> 31) != 0);
+    const char* rec = (const char*)__builtin_assume_aligned((const char*)a.points + (uint64_t)(e & 0x7fffffffu) * a.point_stride, 16);
+    Affine<F> pt = *(const Affine<F>*)rec;
+    bool qinf;   // carry-free fields: the record's flag word (convert_point_body); reference layout: test x and y
+    if constexpr (F::UNSAT) qinf = *(const uint32_t*)(rec + gather_flag_offset<F>()) != 0u; else qinf = pt.is_inf();
+    if (!qinf) xyzz_madd_flag<F>(acc, empty, pt.x, pt.y, (e >> 31) != 0);
   }
+  if (empty) acc = XYZZ<F>::inf();
   const bool started_before = first_run && bs[b] < p0;
   const bool ends_after = bend > p1;
   if (started_before) {

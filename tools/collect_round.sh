@@ -12,29 +12,51 @@ REPO=$PWD
 timeout 600 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
 
 # headline line, un-profiled
-timeout 600 python bench.py --steps 20 --warmup 3 > "$OUT/bench_$TAG.json" 2> "$OUT/bench.err"
+timeout 600 python bench.py > "$OUT/bench_$TAG.json" 2> "$OUT/bench.err"
 
 # kernel trace + stats (rocpd database, summarised by tools/kernel_timeline.py)
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o p -- python "$REPO/bench.py" --steps 10 --warmup 2 \
-    --no-cpu-baseline > "$OUT/bench_${TAG}_under_rocprof.json" 2> "$OUT/prof.log" )
+    --no-cpu-baseline --no-latency > "$OUT/bench_${TAG}_under_rocprof.json" 2> "$OUT/prof.log" )
 DB=$(find "$OUT/prof" -name "*.db" | head -1)
 python tools/kernel_timeline.py "$DB" > "$OUT/rocprof_${TAG}_kernel_stats.txt" 2>> "$OUT/prof.log"
 
 # HBM traffic: one counter per pass, csv output, kernel-trace only
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o p -- python "$REPO/bench.py" \
-      --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.log" )
+      --steps 3 --warmup 1 --no-cpu-baseline --no-latency > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.log" )
 done
 python tools/pmc_summary.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "bls12_381_g1_2^20" "$OUT/hbm_traffic_k_accum.json" \
     "$OUT/pmc_${TAG}_hbm_bytes.txt" > /dev/null 2>> "$OUT/prof.log"
 
+# SQ counters of the accumulate kernel (own passes, kernel-trace only) for the headline and the 254/255-bit fields,
+# and the kernel statistics of those configs
+sq() {  # tag, mixed adds per launch, bench args...
+  local tag=$1 madds=$2; shift 2
+  ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
+      --kernel-trace --output-format csv -d "$OUT/sq1_$tag" -o p -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-latency "$@" > /dev/null 2> "$OUT/sq1_$tag.log" )
+  ( cd /tmp && timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/sq2_$tag" -o p -- \
+      python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-latency "$@" > /dev/null 2> "$OUT/sq2_$tag.log" )
+  { echo "# SQ / GRBM counters of k_accum, bench.py $*, rocprofv3 --pmc (two passes, --kernel-trace only)"; python tools/sq_summary.py k_accum $madds "$OUT/sq1_$tag" "$OUT/sq2_$tag"; } > "$OUT/pmc_${TAG}_sq_counters_k_accum_$tag.txt" 2>> "$OUT/prof.log"
+}
+sq bls12_381_g1_2pow20 16777216
+sq bn254_snarks_g1_2pow22 67108864 --curve bn254_snarks_g1 --log2n 22
+sq pallas_2pow20 16777216 --curve pallas
+for cfg in "bn254_snarks_g1 22" "pallas 20" "bls12_381_g2 20"; do
+  set -- $cfg
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_$1" -o p -- python "$REPO/bench.py" --curve $1 --log2n $2 --steps 10 --warmup 2 \
+      --no-cpu-baseline --no-latency > /dev/null 2>> "$OUT/prof.log" )
+  DB=$(find "$OUT/prof_$1" -name "*.db" | head -1)
+  python tools/kernel_timeline.py "$DB" > "$OUT/rocprof_${TAG}_kernel_stats_$1_2pow$2.txt" 2>> "$OUT/prof.log"
+  find "$OUT/prof_$1" -name "*.db" -delete 2>/dev/null
+done
+
 # the other BASELINE configs and the size sweep
-timeout 300 python bench.py --curve bn254_snarks_g1 --log2n 22 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_bn254_snarks_g1.json" 2>> "$OUT/bench.err"
-timeout 300 python bench.py --curve pallas --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_pallas.json" 2>> "$OUT/bench.err"
-timeout 300 python bench.py --curve vesta --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_vesta.json" 2>> "$OUT/bench.err"
-timeout 300 python bench.py --curve bls12_381_g2 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g2.json" 2>> "$OUT/bench.err"
+timeout 300 python bench.py --curve bn254_snarks_g1 --log2n 22 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bn254_snarks_g1.json" 2>> "$OUT/bench.err"
+timeout 300 python bench.py --curve pallas --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_pallas.json" 2>> "$OUT/bench.err"
+timeout 300 python bench.py --curve vesta --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_vesta.json" 2>> "$OUT/bench.err"
+timeout 300 python bench.py --curve bls12_381_g2 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g2.json" 2>> "$OUT/bench.err"
 for k in 16 18 22 24; do
-  timeout 300 python bench.py --log2n $k --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g1_2pow$k.json" 2>> "$OUT/bench.err"
+  timeout 300 python bench.py --log2n $k --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g1_2pow$k.json" 2>> "$OUT/bench.err"
 done
 timeout 300 python tools/bench_batch_ops.py > "$OUT/batch_ops_$TAG.txt" 2>> "$OUT/bench.err"
 timeout 300 python tools/bench_hostptr.py > "$OUT/hostptr_$TAG.txt" 2>> "$OUT/bench.err"
