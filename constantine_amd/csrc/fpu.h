@@ -58,8 +58,10 @@ struct FpU {
   }
   CTT_HD static FpU select(bool c, const FpU& a, const FpU& b) {
     FpU r;
-#if defined(CTT_FPU_SELECT_BFI)
-    const uint32_t m = 0u - (uint32_t)c;   // v_bfi_b32 instead of v_cndmask_b32 (experiment)
+#if !defined(CTT_FPU_SELECT_CNDMASK)
+    // one v_bfi_b32 per limb; v_cndmask_b32 (lane mask read from an SGPR pair) measured 0.3-0.6 % slower on every curve
+    // (profiles/bench_r02_select_bfi.txt) and 22 cycles per instruction in isolation (profiles/microbench_isa_r02.jsonl)
+    const uint32_t m = 0u - (uint32_t)c;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = (a.l[i] & m) | (b.l[i] & ~m);
 #else

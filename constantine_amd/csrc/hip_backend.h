@@ -60,6 +60,10 @@ __global__ void __launch_bounds__(EC_BLOCK) k_pyr(PyrArgs<F> a, uint32_t ntasks)
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < ntasks) pyr_body<F>(a, blockIdx.y, t);
 }
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
+  bucket_sum_body<F>(sets, nsets, set_elems, blockIdx.x * blockDim.x + threadIdx.x);
+}
 static __global__ void k_iota(uint32_t* entries, uint32_t n, uint32_t* bucket_start, uint32_t* maxcount) {
   iota_body(entries, n, bucket_start, maxcount, blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -272,6 +276,18 @@ struct HipBackend {
     return p;
   }
   void free_host(void* p) { HIP_CHECK(hipHostFree(p)); }
+  // Host -> device on the copy stream: a pageable source keeps the calling thread busy for the duration of the copy but
+  // not the compute queues (profiles/h2d_overlap_r02.jsonl: 56 GB/s with or without a kernel holding every wave slot).
+  hipStream_t cpy = nullptr;
+  hipEvent_t ev_copy = nullptr;
+  void h2d(void* dst, const void* src, size_t b) {
+    if (b) HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyHostToDevice, cpy));
+  }
+  // what is enqueued on the main stream from now on sees the copies made so far
+  void h2d_done() {
+    HIP_CHECK(hipEventRecord(ev_copy, cpy));
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_copy, 0));
+  }
   void d2h_async(int slot, void* dst_pinned, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst_pinned, src, b, hipMemcpyDeviceToHost, cur()));
     HIP_CHECK(hipEventRecord(ev_done[slot], cur()));
@@ -362,6 +378,11 @@ struct HipBackend {
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
+  void launch_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
+    hipLaunchKernelGGL(k_bucket_sum<F>, grid1(set_elems, EC_BLOCK), dim3(EC_BLOCK), 0, stream, sets, nsets, set_elems);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F>
   void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
     // few tasks left: four lanes per addition (the chip is mostly idle, the addition is 3.5x shallower)
     if (pyr_is_narrow(ntasks, W)) {
@@ -388,6 +409,9 @@ struct CurveOps {
   int (*submit)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
                 int* plan);
   int (*finish)(void* eng, int slot, void* r_host, int out_kind);
+  // host-resident inputs, uploaded in slices underneath the accumulation (MsmEngine::submit_host); chunks 0 = automatic
+  int (*submit_host)(void* eng, const MsmOptions* opt, const void* h_coefs, int coef_is_fr, const void* h_points, uint32_t n,
+                     void* d_stage_coefs, void* d_stage_points, int chunks, int* plan);
   // cached bases: device records for `n` points (d_points in the C-API layout, device memory); submit against them
   void* (*bases_prepare)(void* eng, const void* d_points, uint32_t n);
   int (*submit_bases)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_prepared,
@@ -425,6 +449,19 @@ struct CurveImpl {
     if (sl < 0) return sl;
     const MsmPlan& p = e.last_plan;
     plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
+    return sl;
+  }
+  static int submit_host(void* eng, const MsmOptions* opt, const void* h_coefs, int coef_is_fr, const void* h_points, uint32_t n,
+                         void* d_stage_coefs, void* d_stage_points, int chunks, int* plan) {
+    Engine& e = *(Engine*)eng;
+    uint32_t lanes = e.opt.lanes;
+    e.opt = *opt;
+    e.opt.lanes = lanes;
+    int sl = e.submit_host(h_coefs, coef_is_fr != 0, h_points, n, d_stage_coefs, d_stage_points, chunks);
+    if (sl < 0) return sl;
+    const MsmPlan& p = e.last_plan;
+    plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
+    plan[7] = (int)e.last_chunks;
     return sl;
   }
   static void* bases_prepare(void* eng, const void* d_points, uint32_t n) {
@@ -492,7 +529,7 @@ struct CurveImpl {
     HIP_CHECK(hipGetLastError());
   }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F)};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F)};
     return &o;
   }
 };

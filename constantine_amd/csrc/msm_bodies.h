@@ -276,6 +276,20 @@ CTT_HD void merge_final_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sum of the bucket sets of a host-pointer MSM uploaded in slices (MsmEngine::submit_host): sets[0][i] += sets[k][i].
+// ---------------------------------------------------------------------------------------------
+template <class F>
+CTT_HD void bucket_sum_body(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems, uint32_t i) {
+  if (i >= set_elems) return;
+  XYZZ<F> acc = sets[i];
+  for (uint32_t k = 1; k < nsets; k++) {
+    XYZZ<F> y = sets[(uint64_t)k * set_elems + i];
+    acc = xyzz_add_inl<F>(acc, y);
+  }
+  sets[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Bucket reduction  sum_b (b+1) * B_b  per window, in log depth.
 //
 // The reference's bucketReduce (ec_multi_scalar_mul.nim:186-197) is a serial running sum: 2*2^(c-1)

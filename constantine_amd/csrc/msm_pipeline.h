@@ -213,23 +213,22 @@ struct MsmEngine {
     }
   }
 
-  // d_prepared (optional): records made by prepare_bases for the same points; skips the per-MSM conversion.
-  // Returns the slot, or -1 when both slots are in flight.
-  int submit(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n,
-             const void* d_prepared = nullptr) {
-    const int sl = next_slot;
-    Slot& S = slots[sl];
-    if (S.busy) return -1;  // two MSMs in flight already: the caller finishes the oldest first (C ABI: error code)
-    next_slot ^= 1;
-    S.busy = true;
-    S.empty = (n == 0);  // len == 0 is UB upstream (SURVEY §4); we return the neutral
-    if (S.empty) return sl;
-    MsmPlan p = make_plan(n, C::BITS, opt);
-    S.plan = p;
-    last_plan = p;
-    const uint32_t W = p.W, B = p.B;
-
-    bk.stage_begin(sl, ST_TOTAL);
+  // ---- the stages of one MSM ---------------------------------------------------------------------------------------
+  // Stage 1 (per MSM, or per chunk of a host-pointer MSM): scalars -> Booth digits -> entries sorted by bucket ->
+  // bucket sums of these pairs in `d_buckets` (heads/tails of the runs that straddle lane ranges still to be merged).
+  // Ends with the accumulate kernel enqueued; the largest bucket is on its way to the host (merge_buckets needs it).
+  struct Staged {
+    uint32_t* d_bstart;
+    uint32_t* d_maxcount;
+    XYZZ<FD>* d_buckets;
+    XYZZ<FD>* d_heads;
+    XYZZ<FD>* d_tails;
+    uint32_t* d_hkey;
+    uint32_t* d_tkey;
+  };
+  Staged accumulate_pairs(int sl, const MsmPlan& p, const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in,
+                          const void* d_prepared, void* d_converted, XYZZ<FD>* d_buckets) {
+    const uint32_t n = p.n, W = p.W, B = p.B;
     bk.stage_begin(sl, ST_DIGITS);
     const uint32_t* d_scalars = d_coefs;
     if (coef_is_fr) {
@@ -243,9 +242,8 @@ struct MsmEngine {
       if (d_prepared) {
         d_points = d_prepared;
       } else {
-        void* cp = need(cpoints, (size_t)n * gather_stride<FD>());
-        bk.template launch_convert<F, FD>(d_points_in, cp, n);
-        d_points = cp;
+        bk.template launch_convert<F, FD>(d_points_in, d_converted, n);
+        d_points = d_converted;
       }
       point_stride = gather_stride<FD>();
     } else {
@@ -266,13 +264,14 @@ struct MsmEngine {
     sa.cntA = (uint32_t*)need(counts, (size_t)p.S * W * p.NG * 4);
     sa.gtot = (uint32_t*)need(totals, (size_t)W * p.NG * 4);
     sa.gbase = (uint32_t*)need(gbase, (size_t)W * (p.NG + 1) * 4);
-    uint32_t* d_bstart = (uint32_t*)need(bstart, (size_t)W * (B + 1) * 4);
+    Staged st;
+    st.d_bstart = (uint32_t*)need(bstart, (size_t)W * (B + 1) * 4);
     uint32_t* d_entries = (uint32_t*)need(entries, (size_t)W * n * 4);
-    uint32_t* d_maxcount = (uint32_t*)need(maxcount, 256);
-    bk.memset0(d_maxcount, 8);
-    sa.bstart = d_bstart; sa.entries = d_entries; sa.maxcount = d_maxcount;
+    st.d_maxcount = (uint32_t*)need(maxcount, 256);
+    bk.memset0(st.d_maxcount, 8);
+    sa.bstart = st.d_bstart; sa.entries = d_entries; sa.maxcount = st.d_maxcount;
     bk.launch_digits_sort(sa);
-    bk.fetch_u32_async(d_maxcount);  // largest bucket: read back while the accumulation runs
+    bk.fetch_u32_async(st.d_maxcount);  // largest bucket: read back while the accumulation runs
     bk.stage_end(sl, ST_SORT);
 
     // The previous MSM's tail (narrow reduction passes + result copy on the backend's second stream) has had this MSM's
@@ -281,30 +280,38 @@ struct MsmEngine {
     // a slower box: reduce span 2.4 ms, the pipeline slower than the serial order).  Worst case this is the serial order.
     bk.tail_wait();
     bk.stage_begin(sl, ST_ACCUM);
-    XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(buckets, (size_t)W * B * sizeof(XYZZ<FD>));
+    st.d_buckets = d_buckets;
     bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
-    XYZZ<FD>* d_heads = (XYZZ<FD>*)need(heads, (size_t)W * p.G * sizeof(XYZZ<FD>));
-    XYZZ<FD>* d_tails = (XYZZ<FD>*)need(tails, (size_t)W * p.G * sizeof(XYZZ<FD>));
-    uint32_t* d_hkey = (uint32_t*)need(hkey, (size_t)W * p.G * 4);
-    uint32_t* d_tkey = (uint32_t*)need(tkey, (size_t)W * p.G * 4);
-    AccumArgs<FD> aa{d_entries, d_bstart, d_points, point_stride, d_buckets, d_heads, d_tails, d_hkey, d_tkey, n, B, p.K, p.G};
+    st.d_heads = (XYZZ<FD>*)need(heads, (size_t)W * p.G * sizeof(XYZZ<FD>));
+    st.d_tails = (XYZZ<FD>*)need(tails, (size_t)W * p.G * sizeof(XYZZ<FD>));
+    st.d_hkey = (uint32_t*)need(hkey, (size_t)W * p.G * 4);
+    st.d_tkey = (uint32_t*)need(tkey, (size_t)W * p.G * 4);
+    AccumArgs<FD> aa{d_entries, st.d_bstart, d_points, point_stride, d_buckets, st.d_heads, st.d_tails, st.d_hkey, st.d_tkey, n, B, p.K, p.G};
     bk.template launch_accum<FD>(aa, W);
     bk.stage_end(sl, ST_ACCUM);
+    return st;
+  }
 
+  // Stage 2: partial sums of the buckets that straddle lane ranges.  Waits (host) for the largest bucket of stage 1:
+  // a bucket of m entries spans at most floor((m-1)/K)+1 heads, the tree over such a chain takes log2 steps.  With chains
+  // of length one -- the common case, no bucket larger than K -- the tail merge writes the buckets itself.
+  void merge_buckets(int sl, const MsmPlan& p, const Staged& st) {
     bk.stage_begin(sl, ST_MERGE);
-    MergeArgs<FD> ma{d_bstart, d_buckets, d_heads, d_tails, d_hkey, d_tkey, d_maxcount, B, p.K, p.G};
-    // tree steps over the head chain of a bucket: a bucket of m entries spans at most floor((m-1)/K)+1 heads
-    // (the largest bucket was read back while the accumulation ran).  With chains of length one -- the common case,
-    // no bucket larger than K -- the tail merge writes the buckets itself.
+    MergeArgs<FD> ma{st.d_bstart, st.d_buckets, st.d_heads, st.d_tails, st.d_hkey, st.d_tkey, st.d_maxcount, p.B, p.K, p.G};
     const uint32_t mc = bk.fetch_u32_wait();
     const uint32_t chain = mc ? (mc - 1) / p.K + 1 : 0;
-    bk.template launch_merge_tail<FD>(ma, W, chain <= 1);
+    bk.template launch_merge_tail<FD>(ma, p.W, chain <= 1);
     if (chain > 1) {
-      for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<FD>(ma, W, d);
-      bk.template launch_merge_final<FD>(ma, W);
+      for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<FD>(ma, p.W, d);
+      bk.template launch_merge_final<FD>(ma, p.W);
     }
     bk.stage_end(sl, ST_MERGE);
+  }
 
+  // Stage 3: bucket reduction (c-1 pyramid passes) and the copy of the c points per window to the slot's pinned buffer.
+  void reduce_buckets(int sl, const MsmPlan& p, XYZZ<FD>* d_buckets) {
+    Slot& S = slots[sl];
+    const uint32_t W = p.W, B = p.B;
     bk.stage_begin(sl, ST_REDUCE);
     XYZZ<FD>* d_pyr = (XYZZ<FD>*)need(rA[0], (size_t)W * B * sizeof(XYZZ<FD>));
     XYZZ<FD>* d_q = (XYZZ<FD>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<FD>));
@@ -333,8 +340,95 @@ struct MsmEngine {
     bk.d2h_async(sl, S.hraw, d_out, bytes);
     bk.stage_end(sl, ST_TOTAL);
     if (forked) bk.tail_end();
+  }
+
+  int claim_slot(uint32_t n) {
+    const int sl = next_slot;
+    Slot& S = slots[sl];
+    if (S.busy) return -1;  // two MSMs in flight already: the caller finishes the oldest first (C ABI: error code)
+    next_slot ^= 1;
+    S.busy = true;
+    S.empty = (n == 0);  // len == 0 is UB upstream (SURVEY §4); we return the neutral
     return sl;
   }
+
+  // One MSM on device-resident inputs.  d_prepared (optional): records made by prepare_bases for the same points; skips
+  // the per-MSM conversion.  Returns the slot, or -1 when both slots are in flight.
+  int submit(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n,
+             const void* d_prepared = nullptr) {
+    const int sl = claim_slot(n);
+    if (sl < 0 || n == 0) return sl;
+    const MsmPlan p = make_plan(n, C::BITS, opt);
+    slots[sl].plan = p;
+    last_plan = p;
+    bk.stage_begin(sl, ST_TOTAL);
+    void* d_converted = nullptr;
+    if constexpr (kConvert) {
+      if (!d_prepared) d_converted = need(cpoints, (size_t)n * gather_stride<FD>());
+    }
+    XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(buckets, (size_t)p.W * p.B * sizeof(XYZZ<FD>));
+    const Staged st = accumulate_pairs(sl, p, d_coefs, coef_is_fr, d_points_in, d_prepared, d_converted, d_buckets);
+    merge_buckets(sl, p, st);
+    reduce_buckets(sl, p, d_buckets);
+    return sl;
+  }
+
+  // One MSM on HOST-resident inputs (what the Constantine C symbols hand over), uploaded in `chunks` slices of pairs so
+  // that the upload of slice i+1 runs underneath the accumulation of slice i: the copies go through the backend's copy
+  // stream (a pageable hipMemcpyAsync occupies the calling thread but not the GPU's compute queues, and runs at PCIe
+  // speed while k_accum holds every wave slot: profiles/h2d_overlap_r02.jsonl).  Every slice is sorted and accumulated
+  // into its own bucket set (one owner per bucket per launch, no atomics); the sets are summed before the one bucket
+  // reduction.  d_stage_coefs / d_stage_points: device staging for all n pairs (caller-owned).  Blocking on the copies,
+  // asynchronous from the last accumulation on; returns the slot, or -1 when both slots are in flight.
+  static uint32_t host_chunks(uint32_t n, int want) {
+    // automatic: slices of about 2^19 pairs (a 64 MiB upload hides under the previous slice's accumulation; every extra
+    // slice costs one more sort launch sequence and one more addition per bucket); an explicit request is honoured
+    uint32_t cch = want > 0 ? (uint32_t)want : (n >= (3u << 20) ? 4u : n >= (3u << 18) ? 2u : 1u);
+    if (cch > 8) cch = 8;
+    if (cch > n) cch = n;
+    return cch < 1 ? 1 : cch;
+  }
+  int submit_host(const void* h_coefs, bool coef_is_fr, const void* h_points, uint32_t n, void* d_stage_coefs,
+                  void* d_stage_points, int want_chunks) {
+    const int sl = claim_slot(n);
+    if (sl < 0 || n == 0) return sl;
+    const uint32_t nch = host_chunks(n, want_chunks);
+    const uint32_t base = n / nch, cutoff = n % nch;   // balanced slices (partitioners.nim:44-77)
+    MsmOptions o = opt;
+    if (o.c <= 0) o.c = choose_window_bits(n, C::BITS, o.lanes);  // one window size for the whole MSM
+    bk.stage_begin(sl, ST_TOTAL);
+    const MsmPlan p0 = make_plan(base + (cutoff ? 1 : 0), C::BITS, o);   // the largest slice sizes the workspace
+    const size_t set = (size_t)p0.W * p0.B;
+    XYZZ<FD>* d_sets = (XYZZ<FD>*)need(buckets, (size_t)nch * set * sizeof(XYZZ<FD>));
+    void* d_conv_all = nullptr;
+    if constexpr (kConvert) d_conv_all = need(cpoints, (size_t)n * gather_stride<FD>());
+    MsmPlan plast = p0;
+    Staged st_prev{};
+    MsmPlan p_prev = p0;
+    for (uint32_t i = 0; i < nch; i++) {
+      const uint32_t start = i * base + (i < cutoff ? i : cutoff), cnt = base + (i < cutoff ? 1 : 0);
+      uint32_t* d_c = (uint32_t*)d_stage_coefs + (size_t)start * 8;
+      Affine<F>* d_p = (Affine<F>*)d_stage_points + start;
+      bk.h2d(d_c, (const char*)h_coefs + (size_t)start * 32, (size_t)cnt * 32);                   // the GPU works on slice i-1 meanwhile
+      bk.h2d(d_p, (const char*)h_points + (size_t)start * sizeof(Affine<F>), (size_t)cnt * sizeof(Affine<F>));
+      bk.h2d_done();                                                                              // main stream waits for the copies
+      if (i > 0) merge_buckets(sl, p_prev, st_prev);   // slice i-1's merge goes in front of slice i's kernels (shared workspace)
+      const MsmPlan p = make_plan(cnt, C::BITS, o);
+      void* d_conv = kConvert ? (void*)((char*)d_conv_all + (size_t)start * gather_stride<FD>()) : nullptr;
+      st_prev = accumulate_pairs(sl, p, d_c, coef_is_fr, d_p, nullptr, d_conv, d_sets + (size_t)i * set);
+      p_prev = p;
+      plast = p;
+    }
+    merge_buckets(sl, p_prev, st_prev);
+    if (nch > 1) bk.template launch_bucket_sum<FD>(d_sets, nch, (uint32_t)set);
+    plast.n = n;
+    slots[sl].plan = plast;
+    last_plan = plast;
+    last_chunks = nch;
+    reduce_buckets(sl, plast, d_sets);
+    return sl;
+  }
+  uint32_t last_chunks = 1;
 
   // Host tail of a submitted MSM: wait for its device output, Horner over (window, bit).
   XYZZ<HF> finish(int sl) {

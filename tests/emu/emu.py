@@ -28,6 +28,7 @@ def lib():
         L.emu_field_op.argtypes = [i32, i32, vp, vp, vp]
         L.emu_field_op_dev.argtypes = [i32, i32, vp, vp, vp]
         L.emu_dev_field_info.argtypes = [i32, vp, vp]
+        L.emu_msm_host.argtypes = [i32, i32, i32, vp, vp, vp, sz, i32, i32]
         L.emu_sum_reduce.argtypes = [i32, i32, vp, vp, sz, i32]
         L.emu_batch_affine.argtypes = [i32, i32, vp, vp, sz, i32]
         _lib = L
@@ -48,6 +49,19 @@ def msm(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, K=0, S=0):
     rc = lib().emu_msm(CURVE_ID[curve], int(coef_is_fr), out_kind, _p(out), _p(coefs), _p(points), n, c, K, S, _p(plan))
     assert rc == 0
     return out, plan
+
+
+def msm_host(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, chunks=0):
+    """The host-pointer form of the engine (MsmEngine::submit_host): inputs uploaded in slices, one bucket set per slice.
+    Returns (result, slices used)."""
+    coefs = np.ascontiguousarray(coefs, dtype=np.uint8)
+    points = np.ascontiguousarray(points, dtype=np.uint8)
+    n = coefs.shape[0]
+    nco = 2 if out_kind == 0 else 3
+    out = np.zeros(AFF_BYTES[curve] // 2 * nco, dtype=np.uint8)
+    used = lib().emu_msm_host(CURVE_ID[curve], int(coef_is_fr), out_kind, _p(out), _p(coefs), _p(points), n, c, chunks)
+    assert used >= 1
+    return out, used
 
 
 def gen_points(curve, seed, n, first=0):

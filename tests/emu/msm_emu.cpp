@@ -26,6 +26,12 @@ struct EmuBackend {
   void tail_wait() {}
   static bool pyr_goes_to_tail(uint32_t, uint32_t) { return false; }
   void d2h_sync(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
+  void h2d(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
+  void h2d_done() {}
+  template <class F>
+  void launch_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
+    for (uint32_t i = 0; i < set_elems; i++) bucket_sum_body<F>(sets, nsets, set_elems, i);
+  }
   void launch_iota(uint32_t* entries, uint32_t n, uint32_t* bstart, uint32_t* maxcount) {
     for (uint32_t j = 0; j < (n ? n : 1); j++) iota_body(entries, n, bstart, maxcount, j);
   }
@@ -98,6 +104,8 @@ struct EmuBackend {
 struct EmuOps {
   int (*msm)(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c, int K,
              int S, int* plan_out);
+  // host-pointer form: the inputs are uploaded in `chunks` slices, one bucket set per slice (MsmEngine::submit_host)
+  int (*msm_host)(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c, int chunks);
   void (*gen)(uint64_t seed, uint64_t first, uint32_t n, void* out);
   void (*fop)(int op, const void* a, const void* b, void* r);
   int (*fop_dev)(int op, const void* a, const void* b, void* r);
@@ -138,6 +146,17 @@ struct EmuCurve {
       plan_out[3] = (int)eng.last_plan.G; plan_out[4] = (int)eng.last_plan.S;
     }
     return 0;
+  }
+  static int msm_host(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c, int chunks) {
+    EmuBackend bk;
+    MsmEngine<C, EmuBackend> eng(bk);
+    eng.opt.c = c;
+    eng.opt.lanes = 4096;
+    std::vector<unsigned char> sc(n * 32 + 64), sp(n * sizeof(Affine<F>) + 64);
+    int s0 = eng.submit_host(coefs, coef_is_fr != 0, points, (uint32_t)n, sc.data(), sp.data(), chunks);
+    auto res = eng.finish(s0);
+    write_result<typename MsmEngine<C, EmuBackend>::HF>(r, res, out_kind);
+    return (int)eng.last_chunks;
   }
   static void gen(uint64_t seed, uint64_t first, uint32_t n, void* out) {
     Affine<F> G = generator<C>();
@@ -188,7 +207,7 @@ struct EmuCurve {
     for (uint32_t lane = 0; (uint64_t)lane * K < n; lane++) batch_affine_body<F>(a, lane);
   }
   static const EmuOps* ops() {
-    static const EmuOps o = {msm, gen, fop, fop_dev, dev_info, sum_reduce, batch_affine};
+    static const EmuOps o = {msm, msm_host, gen, fop, fop_dev, dev_info, sum_reduce, batch_affine};
     return &o;
   }
 };
@@ -233,6 +252,11 @@ int emu_msm(int curve, int coef_is_fr, int out_kind, void* r, const void* coefs,
             int K, int S, int* plan_out) {
   const EmuOps* o = ops_of(curve);
   return o ? o->msm(coef_is_fr, out_kind, r, coefs, points, n, c, K, S, plan_out) : -1;
+}
+int emu_msm_host(int curve, int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c,
+                 int chunks) {
+  const EmuOps* o = ops_of(curve);
+  return o ? o->msm_host(coef_is_fr, out_kind, r, coefs, points, n, c, chunks) : -1;
 }
 int emu_gen_points(int curve, uint64_t seed, uint64_t first, uint32_t n, void* out) {
   const EmuOps* o = ops_of(curve);

@@ -222,3 +222,25 @@ def test_fr_coefs_entry(name):
     expect, _ = cref.msm(name, can, pts)
     out, _ = emu.msm(name, mont, pts, coef_is_fr=True, c=4)
     assert bytes(out) == bytes(expect)
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_snarks_g1", "bls12_381_g2"])
+def test_host_pointer_form_uploads_in_slices(name):
+    """MsmEngine::submit_host: the pairs arrive in slices, every slice is sorted and accumulated into its own bucket set,
+    the sets are summed before the one bucket reduction -- same element for any number of slices (1, 2, 3, 8; ragged
+    slice sizes; slices that leave whole buckets empty; Fr Montgomery coefficients)."""
+    curve = po.CURVES[name]
+    n = 1201 if curve.F.degree == 1 else 150
+    pts = cref.gen_points(name, 501, n)
+    sc = cref.synth_scalars(502, n, curve.scalar_bits)
+    sc[:40] = sc[0]                      # one heavy bucket per window that lives in the first slice only
+    pts[7] = 0                           # a neutral point
+    expect, _ = cref.msm(name, sc, pts)
+    for chunks, c in ((1, 0), (2, 0), (3, 5), (8, 0), (2, 11)):
+        out, used = emu.msm_host(name, sc, pts, c=c, chunks=chunks)
+        assert bytes(out) == bytes(expect), (name, chunks, c)
+        assert used == chunks
+    mont = cref.synth_scalars(503, n, 250)
+    expect, _ = cref.msm(name, cref.fr_from_mont(name, mont), pts)
+    out, _ = emu.msm_host(name, mont, pts, coef_is_fr=True, chunks=3)
+    assert bytes(out) == bytes(expect)

@@ -467,6 +467,29 @@ def test_two_msms_in_flight(dev, torch_cuda):
         pending = nxt
 
 
+def test_host_symbols_upload_in_slices():
+    """The host-pointer symbols upload the pairs in slices underneath the accumulation, one bucket set per slice
+    (MsmEngine::submit_host): same element for 1, 2, 3, 4, 8 slices and for the automatic choice, ragged sizes."""
+    from constantine_amd import _lib, multiScalarMul_vartime, multiScalarMul_vartime_parallel
+    L = _lib.lib()
+    try:
+        for name, n in (("bls12_381_g1", (1 << 20) + 3), ("bn254_snarks_g1", 300001), ("bls12_381_g2", 40000), ("pallas", 7)):
+            curve = po.CURVES[name]
+            pts = cref.gen_points(name, 600 + n, n)
+            sc = cref.synth_scalars(601 + n, n, curve.scalar_bits)
+            expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
+            for chunks in ((0, 1, 2, 3, 4, 8) if n > 100000 else (0, 2, 3)):
+                assert L.ctt_hip_msm_set_option(None, b"chunks", chunks) == 0
+                assert _decode(curve, "jac", multiScalarMul_vartime(name, sc, pts, coord="jac")) == expect, (name, chunks)
+            if name == "bn254_snarks_g1":
+                mont = cref.synth_scalars(602, n, 253)
+                exp2 = _aff(curve, cref.msm(name, cref.fr_from_mont(name, mont), pts, nthreads=NT)[0])
+                L.ctt_hip_msm_set_option(None, b"chunks", 3)
+                assert _decode(curve, "prj", multiScalarMul_vartime_parallel(None, name, mont, pts, coord="prj", fr_coefs=True)) == exp2
+    finally:
+        L.ctt_hip_msm_set_option(None, b"chunks", 0)
+
+
 def test_api_misuse_returns_error_codes(dev, torch_cuda):
     """Recoverable misuse of the device-resident interface is an error code (RuntimeError here), not an abort: a third
     ticket on a curve, finishing a ticket twice, a blocking call while two tickets are outstanding, cached bases used
