@@ -183,23 +183,6 @@ __global__ void __launch_bounds__(EC_BLOCK) k_merge_step_quad(MergeArgs<F> a, ui
   XYZZ<F>* h = a.heads + (uint64_t)blockIdx.y * a.G + g;
   xyzz_add_quad<F>(h, h + d, h, (XYZZ<F>*)nullptr, (int)(lane & 3u));
 }
-// the whole head-merging tree of the short chains in one launch (msm_bodies.h merge_chain_*): 2*MERGE_TILE quads per
-// workgroup, one per slot, a workgroup barrier between the levels; `levels` = ceil(log2(longest chain))
-template <class F>
-__global__ void __launch_bounds__(8 * MERGE_TILE) k_merge_chain(MergeArgs<F> a, uint32_t levels) {
-  const uint32_t w = blockIdx.y, j = blockIdx.x;
-  const uint32_t q = threadIdx.x >> 2;
-  const int role = (int)(threadIdx.x & 3u);
-  const uint32_t g = j * MERGE_TILE + q;
-  for (uint32_t l = 0, d = 1; l < levels; l++, d <<= 1) {
-    if (merge_chain_level<F>(a, w, j, g, d)) {   // uniform inside the quad
-      XYZZ<F>* h = a.heads + (uint64_t)w * a.G + g;
-      xyzz_add_quad<F>(h, h + d, h, (XYZZ<F>*)nullptr, role);
-    }
-    __syncthreads();
-  }
-  if (role == 0) merge_chain_store<F>(a, w, j, g);
-}
 template <class C>
 __global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t first, uint32_t n, Affine<typename C::F>* out) {
   Affine<typename C::F> G = generator<C>();
@@ -387,11 +370,6 @@ struct HipBackend {
       return;
     }
     hipLaunchKernelGGL(k_merge_step<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, d);
-    HIP_CHECK(hipGetLastError());
-  }
-  template <class F>
-  void launch_merge_chain(const MergeArgs<F>& a, uint32_t W, uint32_t levels) {
-    hipLaunchKernelGGL(k_merge_chain<F>, dim3((a.G + MERGE_TILE - 1) / MERGE_TILE, W), dim3(8 * MERGE_TILE), 0, stream, a, levels);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>

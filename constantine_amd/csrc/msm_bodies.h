@@ -263,36 +263,6 @@ CTT_HD void merge_step_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint3
   a.heads[slot] = xyzz_add_inl<F>(x, y);
 }
 
-// Short chains in ONE launch: workgroup j of window w owns the chains that start in slots [j*T, (j+1)*T) and end before
-// (j+2)*T (every chain of at most T+1 heads qualifies); its lanes cover the slots [j*T, (j+2)*T), run the same tree level
-// by level with a workgroup barrier in between, and the chain start finally stores the bucket.
-// `owned`: the chain of slot g belongs to workgroup j; s, e = first and last slot of the chain; b = its bucket.
-static constexpr uint32_t MERGE_TILE = 64;   // T: chains of up to 65 heads go through the one-launch path
-template <class F>
-CTT_HD bool merge_chain_of(const MergeArgs<F>& a, uint32_t w, uint32_t j, uint32_t g, uint32_t& s, uint32_t& e, uint32_t& b) {
-  if (g >= a.G) return false;
-  b = a.hkey[(uint64_t)w * a.G + g];
-  if (b == KEY_NONE) return false;
-  const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
-  s = bs[b] / a.K + 1;
-  e = (bs[b + 1] - 1) / a.K;
-  return s >= j * MERGE_TILE && s < (j + 1) * MERGE_TILE && e < (j + 2) * MERGE_TILE;
-}
-// level d of the tree for slot g (true when heads[g] += heads[g+d] is due)
-template <class F>
-CTT_HD bool merge_chain_level(const MergeArgs<F>& a, uint32_t w, uint32_t j, uint32_t g, uint32_t d) {
-  uint32_t s, e, b;
-  if (!merge_chain_of<F>(a, w, j, g, s, e, b)) return false;
-  return ((g - s) % (2 * d)) == 0 && g + d <= e;
-}
-// after the last level: the chain start holds the bucket sum
-template <class F>
-CTT_HD void merge_chain_store(const MergeArgs<F>& a, uint32_t w, uint32_t j, uint32_t g) {
-  uint32_t s, e, b;
-  if (!merge_chain_of<F>(a, w, j, g, s, e, b) || g != s) return;
-  a.buckets[(uint64_t)w * a.B + b] = a.heads[(uint64_t)w * a.G + g];
-}
-
 // the first head of each chain now holds the bucket sum
 template <class F>
 CTT_HD void merge_final_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {

@@ -301,12 +301,7 @@ struct MsmEngine {
     const uint32_t mc = bk.fetch_u32_wait();
     const uint32_t chain = mc ? (mc - 1) / p.K + 1 : 0;
     bk.template launch_merge_tail<FD>(ma, p.W, chain <= 1);
-    if (chain > 1 && chain <= MERGE_TILE + 1) {
-      // short chains: the whole tree and the final store in one launch (a workgroup barrier between the levels)
-      uint32_t levels = 0;
-      while ((1u << levels) < chain) levels++;
-      bk.template launch_merge_chain<FD>(ma, p.W, levels);
-    } else if (chain > 1) {
+    if (chain > 1) {
       for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<FD>(ma, p.W, d);
       bk.template launch_merge_final<FD>(ma, p.W);
     }

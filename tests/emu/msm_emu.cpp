@@ -87,22 +87,6 @@ struct EmuBackend {
     for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_step_body<F>(a, w, g, d);
   }
   template <class F>
-  void launch_merge_chain(const MergeArgs<F>& a, uint32_t W, uint32_t levels) {
-    const uint32_t nwg = (a.G + MERGE_TILE - 1) / MERGE_TILE;
-    for (uint32_t w = 0; w < W; w++)
-      for (uint32_t j = 0; j < nwg; j++) {
-        for (uint32_t l = 0, d = 1; l < levels; l++, d <<= 1)
-          for (uint32_t q = 0; q < 2 * MERGE_TILE; q++) {
-            const uint32_t g = j * MERGE_TILE + q;
-            if (!merge_chain_level<F>(a, w, j, g, d)) continue;
-            XYZZ<F>* h = a.heads + (uint64_t)w * a.G + g;
-            XYZZ<F> x = h[0], y = h[d];
-            h[0] = xyzz_add_inl<F>(x, y);
-          }
-        for (uint32_t q = 0; q < 2 * MERGE_TILE; q++) merge_chain_store<F>(a, w, j, j * MERGE_TILE + q);
-      }
-  }
-  template <class F>
   void launch_merge_final(const MergeArgs<F>& a, uint32_t W) {
     for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_final_body<F>(a, w, g);
   }
