@@ -81,16 +81,19 @@ __global__ void __launch_bounds__(EC_BLOCK) k_batch_affine(BatchAffineArgs<F> a)
 //   round 3   PPP = P*PP       Q = U1*PP        ZZ3 = Z2*PP       -
 //   round 4   A = R*(Q-X3)     Bv = S1*PPP      -                 ZZZ3 = Z3*PPP         (X3 = RR-PPP-2Q, Y3 = A-Bv)
 // Exceptional inputs (a neutral operand, P = +-Q) are rare here: lane 0 of the quad then runs the ordinary addition.
-template <class F>
-__device__ __forceinline__ F quad_bcast(const F& v, int src_role) {
-  const int src = (int)((threadIdx.x & ~3u) | (uint32_t)src_role) & 63;
+// value of lane ROLE of the quad, in every lane of the quad: one v_mov_b32 with a DPP quad_perm per limb (full rate; the
+// first version went through ds_bpermute_b32, an LDS-crossbar instruction per limb)
+template <int ROLE, class F>
+__device__ __forceinline__ F quad_bcast(const F& v) {
   F r;
   if constexpr (IsFp2<F>::value) {
-    r.c0 = quad_bcast(v.c0, src_role);
-    r.c1 = quad_bcast(v.c1, src_role);
+    r.c0 = quad_bcast<ROLE>(v.c0);
+    r.c1 = quad_bcast<ROLE>(v.c1);
   } else {
+    constexpr int ctrl = ROLE | (ROLE << 2) | (ROLE << 4) | (ROLE << 6);   // quad_perm:[ROLE,ROLE,ROLE,ROLE]
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(F) / 4); i++) r.l[i] = (uint32_t)__shfl((int)v.l[i], src, 64);
+    for (int i = 0; i < (int)(sizeof(F) / 4); i++)
+      r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], ctrl, 0xf, 0xf, false);
   }
   return r;
 }
@@ -109,10 +112,10 @@ __device__ __forceinline__ void xyzz_add_quad(const XYZZ<F>* s1, const XYZZ<F>* 
     const F opA = fromq ? Q[hi] : A[hi];          // a.x | q.x | a.y | q.y
     const F opB = fromq ? A[2 + hi] : Q[2 + hi];  // q.zz | a.zz | q.zzz | a.zzz
     const F T1 = F::mul(opA, opB);
-    U1 = quad_bcast<F>(T1, 0);
-    U2 = quad_bcast<F>(T1, 1);
-    S1 = quad_bcast<F>(T1, 2);
-    S2 = quad_bcast<F>(T1, 3);
+    U1 = quad_bcast<0>(T1);
+    U2 = quad_bcast<1>(T1);
+    S1 = quad_bcast<2>(T1);
+    S2 = quad_bcast<3>(T1);
     P = fsub<F, M>(U2, U1);  // < 2M
     R = fsub<F, M>(S2, S1);  // < 2M
     plain = fis_zero_modp<F, 2 * M>(P);
@@ -130,15 +133,15 @@ __device__ __forceinline__ void xyzz_add_quad(const XYZZ<F>* s1, const XYZZ<F>* 
   const F za = A[zi], zq = Q[zi];
   const F PR = F::select(role == 0, P, R);
   const F T2 = F::mul(F::select(role < 2, PR, za), F::select(role < 2, PR, zq));  // PP | RR | Z2 | Z3
-  const F PP = quad_bcast<F>(T2, 0);
-  const F RR = quad_bcast<F>(T2, 1);
+  const F PP = quad_bcast<0>(T2);
+  const F RR = quad_bcast<1>(T2);
   const F T3 = F::mul(F::select(role == 0, P, F::select(role == 1, U1, T2)), PP);  // PPP | Q | ZZ3 | (unused)
-  const F PPP = quad_bcast<F>(T3, 0);
-  const F Qv = quad_bcast<F>(T3, 1);
+  const F PPP = quad_bcast<0>(T3);
+  const F Qv = quad_bcast<1>(T3);
   const F X3 = fsub<F, 2 * M>(fsub<F, M>(RR, PPP), F::dbl(Qv));  // < 4M
   const F T4 = F::mul(F::select(role == 0, R, F::select(role == 1, S1, T2)),
                       F::select(role == 0, fsub<F, 4 * M>(Qv, X3), PPP));        // A | Bv | (unused) | ZZZ3
-  const F Bv = quad_bcast<F>(T4, 1);
+  const F Bv = quad_bcast<1>(T4);
   if (role == 0) {
     const F Y3 = fsub<F, M>(T4, Bv);  // < 2M
     d1->x = X3;
@@ -151,6 +154,79 @@ __device__ __forceinline__ void xyzz_add_quad(const XYZZ<F>* s1, const XYZZ<F>* 
     d1->zzz = T4;
     if (d2) d2->zzz = T4;
   }
+}
+
+// --- window sums on the device: S_w = sum_l 2^l O_l + TOP, one quad per window -------------------------------------
+// The bucket reduction leaves c points per window (O_0 .. O_{c-2}: the sums of the buckets whose index has bit l set, and
+// TOP: the sum of all buckets).  Their combination is a Horner over the bits, r = 2r + O_l: a chain of c-1 doublings
+// and c additions.  It used to run on the host together with the Horner over the windows; here one quad per window
+// walks it with the accumulator resident in registers (every lane of the quad holds a full copy): a doubling is 3 rounds
+// of independent products, an addition 4 -- and the host is left with W points and the W*c doublings that join them.
+//   doubling  round 1   V = U^2 (U = 2Y)   XX = X^2         -                -
+//             round 2   Wv = U*V           S = X*V          MM = Mm^2        -              (Mm = 3 XX)
+//             round 3   A = Mm*(S-X3)      Bv = Wv*Y        ZZ3 = V*ZZ       ZZZ3 = Wv*ZZZ  (X3 = MM - 2S, Y3 = A - Bv)
+template <class F>
+__device__ __forceinline__ F quad_pick(int role, const F& a, const F& b, const F& c, const F& d) {
+  return F::select(role < 2, F::select(role == 0, a, b), F::select(role == 2, c, d));
+}
+template <class F>
+__device__ __forceinline__ void xyzz_dbl_quad_reg(XYZZ<F>& p, int role) {
+  constexpr int M = F::MULB;
+  if (p.is_inf()) return;  // uniform inside the quad
+  const F U = F::dbl(p.y);                                            // < 4M
+  const F T1 = F::sqr(F::select(role == 0, U, p.x));                  // V | XX | - | -
+  const F V = quad_bcast<0>(T1), XX = quad_bcast<1>(T1);
+  const F Mm = F::add(F::dbl(XX), XX);                                // < 3M
+  const F T2 = F::mul(quad_pick<F>(role, U, p.x, Mm, Mm), quad_pick<F>(role, V, V, Mm, Mm));   // Wv | S | MM | -
+  const F Wv = quad_bcast<0>(T2), S = quad_bcast<1>(T2), MM = quad_bcast<2>(T2);
+  const F X3 = fsub<F, 2 * M>(MM, F::dbl(S));                         // < 3M
+  const F T3 = F::mul(quad_pick<F>(role, Mm, Wv, V, Wv), quad_pick<F>(role, fsub<F, 3 * M>(S, X3), p.y, p.zz, p.zzz));
+  const F A = quad_bcast<0>(T3), Bv = quad_bcast<1>(T3);
+  p.x = X3;
+  p.y = fsub<F, M>(A, Bv);                                            // < 2M
+  p.zz = quad_bcast<2>(T3);
+  p.zzz = quad_bcast<3>(T3);
+}
+// acc += q (q from memory), the accumulator in registers; same rounds as xyzz_add_quad
+template <class F>
+__device__ __forceinline__ void xyzz_add_quad_reg(XYZZ<F>& acc, const XYZZ<F>& q, int role) {
+  constexpr int M = F::MULB;
+  if (q.is_inf()) return;
+  if (acc.is_inf()) { acc = q; return; }
+  const F T1 = F::mul(quad_pick<F>(role, acc.x, q.x, acc.y, q.y), quad_pick<F>(role, q.zz, acc.zz, q.zzz, acc.zzz));
+  const F U1 = quad_bcast<0>(T1), U2 = quad_bcast<1>(T1), S1 = quad_bcast<2>(T1), S2 = quad_bcast<3>(T1);
+  const F P = fsub<F, M>(U2, U1), R = fsub<F, M>(S2, S1);             // < 2M
+  if (fis_zero_modp<F, 2 * M>(P)) {                                   // uniform: every lane holds the same values
+    acc = xyzz_add_inl<F>(acc, q);
+    return;
+  }
+  const F T2 = F::mul(quad_pick<F>(role, P, R, acc.zz, acc.zzz), quad_pick<F>(role, P, R, q.zz, q.zzz));   // PP | RR | Z2 | Z3
+  const F PP = quad_bcast<0>(T2), RR = quad_bcast<1>(T2);
+  const F T3 = F::mul(quad_pick<F>(role, P, U1, T2, T2), PP);          // PPP | Q | ZZ3 | (unused)
+  const F PPP = quad_bcast<0>(T3), Qv = quad_bcast<1>(T3);
+  const F X3 = fsub<F, 2 * M>(fsub<F, M>(RR, PPP), F::dbl(Qv));       // < 4M
+  const F T4 = F::mul(quad_pick<F>(role, R, S1, T2, T2), quad_pick<F>(role, fsub<F, 4 * M>(Qv, X3), PPP, PPP, PPP));  // A | Bv | - | ZZZ3
+  const F A = quad_bcast<0>(T4), Bv = quad_bcast<1>(T4);
+  acc.x = X3;
+  acc.y = fsub<F, M>(A, Bv);                                          // < 2M
+  acc.zz = quad_bcast<2>(T3);
+  acc.zzz = quad_bcast<3>(T4);
+}
+// out[w][0..c) -> wsum[w]; one workgroup of 64 lanes per window, the first quad works
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_window_sums(const XYZZ<F>* out, XYZZ<F>* wsum, int c) {
+  if (threadIdx.x >= 4) return;
+  const int role = (int)threadIdx.x;
+  const XYZZ<F>* o = out + (size_t)blockIdx.x * c;
+  XYZZ<F> r = XYZZ<F>::inf();
+  for (int l = c - 2; l >= 0; l--) {
+    xyzz_dbl_quad_reg<F>(r, role);
+    const XYZZ<F> y = o[l];
+    xyzz_add_quad_reg<F>(r, y, role);
+  }
+  const XYZZ<F> top = o[c - 1];
+  xyzz_add_quad_reg<F>(r, top, role);
+  if (role == 0) wsum[blockIdx.x] = r;
 }
 
 template <class F>
@@ -380,6 +456,11 @@ struct HipBackend {
   template <class F>
   void launch_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
     hipLaunchKernelGGL(k_bucket_sum<F>, grid1(set_elems, EC_BLOCK), dim3(EC_BLOCK), 0, stream, sets, nsets, set_elems);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F>
+  void launch_window_sums(const XYZZ<F>* out, XYZZ<F>* wsum, uint32_t W, int c) {
+    hipLaunchKernelGGL(k_window_sums<F>, dim3(W), dim3(EC_BLOCK), 0, cur(), out, wsum, c);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>

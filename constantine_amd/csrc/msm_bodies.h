@@ -302,7 +302,7 @@ CTT_HD void bucket_sum_body(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems, u
 // blocks of 2^l buckets), and O_l = sum of the odd-indexed elements of level l.  Total work is 2*2^(c-1)
 // additions (same as the running sum) but the depth is c-1 additions.  Pass p builds pyramid level p+1,
 // starts the odd-element tree of level p and halves the trees of the earlier levels.  The host finishes
-// with one Horner over (window, bit) -- see combine_windows_bits in msm_pipeline.h.
+// with a Horner over the bits of each window (on the device, k_window_sums) and over the windows (msm_pipeline.h).
 // ---------------------------------------------------------------------------------------------
 template <class F>
 struct PyrArgs {

@@ -132,19 +132,27 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   return p;
 }
 
-// Final Horner (ec_multi_scalar_mul.nim:250-254; _parallel.nim:199-203), fused with the last step of the
-// bucket reduction: per window the device returns O_0..O_{c-2} (sum of the buckets whose index has bit l set)
-// and TOP (sum of all buckets); window sum = sum_l 2^l O_l + TOP, result = sum_w 2^(c*w) * window sum.
+// Window combine (ec_multi_scalar_mul.nim:250-254; _parallel.nim:199-203), in two parts.
+// On the device, fused with the last step of the bucket reduction: per window the reduction leaves O_0..O_{c-2} (sum of
+// the buckets whose index has bit l set) and TOP (sum of all buckets); window sum S_w = sum_l 2^l O_l + TOP
+// (window_sum_body, one quad per window on the GPU).  On the host: result = sum_w 2^(c*w) S_w, a Horner whose W*c
+// doublings form one dependent chain -- 0.6 us per doubling on a CPU core against 3.6 us for four GPU lanes.
 template <class F>
-static inline XYZZ<F> combine_windows_bits(const XYZZ<F>* o, int W, int c) {
+CTT_HD XYZZ<F> window_sum_body(const XYZZ<F>* ow, int c) {
+  XYZZ<F> r = XYZZ<F>::inf();
+  for (int l = c - 2; l >= 0; l--) {
+    r = xyzz_dbl<F>(r);
+    xyzz_add<F>(r, ow[l]);
+  }
+  xyzz_add<F>(r, ow[c - 1]);
+  return r;
+}
+template <class F>
+static inline XYZZ<F> combine_windows(const XYZZ<F>* s, int W, int c) {
   XYZZ<F> r = XYZZ<F>::inf();
   for (int w = W - 1; w >= 0; w--) {
-    const XYZZ<F>* ow = o + (size_t)w * c;
-    for (int l = c - 1; l >= 0; l--) {
-      r = xyzz_dbl<F>(r);
-      if (l <= c - 2) xyzz_add<F>(r, ow[l]);
-    }
-    xyzz_add<F>(r, ow[c - 1]);
+    for (int l = 0; l < c; l++) r = xyzz_dbl<F>(r);
+    xyzz_add<F>(r, s[w]);
   }
   return r;
 }
@@ -308,7 +316,7 @@ struct MsmEngine {
     bk.stage_end(sl, ST_MERGE);
   }
 
-  // Stage 3: bucket reduction (c-1 pyramid passes) and the copy of the c points per window to the slot's pinned buffer.
+  // Stage 3: bucket reduction (c-1 pyramid passes), window sums, and their copy to the slot's pinned buffer.
   void reduce_buckets(int sl, const MsmPlan& p, XYZZ<FD>* d_buckets) {
     Slot& S = slots[sl];
     const uint32_t W = p.W, B = p.B;
@@ -329,15 +337,18 @@ struct MsmEngine {
       }
       bk.template launch_pyr<FD>(pa, W, ntasks);
     }
+    // the window sums (Horner over the c points of every window) complete the device part of the combine
+    XYZZ<FD>* d_wsum = (XYZZ<FD>*)need(rP[1], (size_t)W * sizeof(XYZZ<FD>));
+    bk.template launch_window_sums<FD>(d_out, d_wsum, W, p.c);
     bk.stage_end(sl, ST_REDUCE);
 
-    const size_t bytes = (size_t)W * p.c * sizeof(XYZZ<FD>);
+    const size_t bytes = (size_t)W * sizeof(XYZZ<FD>);
     if (bytes > S.hcap) {
       if (S.hraw) bk.free_host(S.hraw);
       S.hraw = bk.alloc_host(bytes);
       S.hcap = bytes;
     }
-    bk.d2h_async(sl, S.hraw, d_out, bytes);
+    bk.d2h_async(sl, S.hraw, d_wsum, bytes);
     bk.stage_end(sl, ST_TOTAL);
     if (forked) bk.tail_end();
   }
@@ -432,7 +443,7 @@ struct MsmEngine {
   }
   uint32_t last_chunks = 1;
 
-  // Host tail of a submitted MSM: wait for its device output, Horner over (window, bit).
+  // Host tail of a submitted MSM: wait for its W window sums, Horner over the windows.
   XYZZ<HF> finish(int sl) {
     Slot& S = slots[sl];
     if (!S.busy) {
@@ -444,10 +455,10 @@ struct MsmEngine {
     bk.d2h_wait(sl);
     const MsmPlan& p = S.plan;
     const XYZZ<FD>* raw = (const XYZZ<FD>*)S.hraw;
-    const size_t cnt = (size_t)p.W * p.c;
+    const size_t cnt = (size_t)p.W;
     std::vector<XYZZ<HF>> sums(cnt);
     for (size_t i = 0; i < cnt; i++) sums[i] = xyzz_to_host<FD>(raw[i]);
-    return combine_windows_bits<HF>(sums.data(), p.W, p.c);
+    return combine_windows<HF>(sums.data(), p.W, p.c);
   }
 
   bool in_flight(int sl) const { return sl >= 0 && sl < 2 && slots[sl].busy; }

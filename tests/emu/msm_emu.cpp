@@ -91,6 +91,10 @@ struct EmuBackend {
     for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_final_body<F>(a, w, g);
   }
   template <class F>
+  void launch_window_sums(const XYZZ<F>* out, XYZZ<F>* wsum, uint32_t W, int c) {
+    for (uint32_t w = 0; w < W; w++) wsum[w] = window_sum_body<F>(out + (size_t)w * c, c);
+  }
+  template <class F>
   void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
     // a pass reads only what earlier passes wrote, except the in-place halving q[t] += q[t+n] (disjoint t)
     for (uint32_t w = 0; w < W; w++) for (uint32_t t = 0; t < ntasks; t++) pyr_body<F>(a, w, t);

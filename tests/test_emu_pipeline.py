@@ -244,3 +244,21 @@ def test_host_pointer_form_uploads_in_slices(name):
     expect, _ = cref.msm(name, cref.fr_from_mont(name, mont), pts)
     out, _ = emu.msm_host(name, mont, pts, coef_is_fr=True, chunks=3)
     assert bytes(out) == bytes(expect)
+
+
+def test_head_chains_of_every_length_class():
+    """Buckets that span several accumulate lanes leave a chain of partial sums (heads) that the merge tree sums in
+    log2(chain) steps: chains of 3 ... 250 heads next to ordinary buckets."""
+    name = "bn254_snarks_g1"
+    K = 4
+    rng = np.random.default_rng(5)
+    for n_equal in (9, 130, 255, 258, 262, 1000):       # chains of 3, 33, 64, 65, 66, 250 heads
+        n = n_equal + 300
+        pts = cref.gen_points(name, 700 + n_equal, n)
+        sc = cref.synth_scalars(701 + n_equal, n, 254)
+        idx = rng.permutation(n)[:n_equal]
+        sc[idx] = sc[idx[0]]                              # n_equal pairs share every bucket; the rest is spread out
+        expect, _ = cref.msm(name, sc, pts)
+        for c in (5, 9):
+            out, plan = emu.msm(name, sc, pts, c=c, K=K)
+            assert bytes(out) == bytes(expect), (n_equal, c)
