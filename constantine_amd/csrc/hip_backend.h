@@ -93,7 +93,10 @@ __device__ __forceinline__ F quad_bcast(const F& v) {
     constexpr int ctrl = ROLE | (ROLE << 2) | (ROLE << 4) | (ROLE << 6);   // quad_perm:[ROLE,ROLE,ROLE,ROLE]
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(F) / 4); i++)
-      r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], ctrl, 0xf, 0xf, false);
+      // `old` = the value itself (every lane of a quad is active whenever this runs): with a constant `old` hipcc's DPP
+      // combine folds the move into a neighbouring subtraction and gets the operand order of a - dpp(b) wrong when both
+      // are the same register (y came out negated in the window-sum kernel: tools/quad_probe.hip)
+      r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)v.l[i], (int)v.l[i], ctrl, 0xf, 0xf, false);
   }
   return r;
 }
@@ -181,9 +184,10 @@ __device__ __forceinline__ void xyzz_dbl_quad_reg(XYZZ<F>& p, int role) {
   const F Wv = quad_bcast<0>(T2), S = quad_bcast<1>(T2), MM = quad_bcast<2>(T2);
   const F X3 = fsub<F, 2 * M>(MM, F::dbl(S));                         // < 3M
   const F T3 = F::mul(quad_pick<F>(role, Mm, Wv, V, Wv), quad_pick<F>(role, fsub<F, 3 * M>(S, X3), p.y, p.zz, p.zzz));
-  const F A = quad_bcast<0>(T3), Bv = quad_bcast<1>(T3);
+  const F Bv = quad_bcast<1>(T3);
+  const F Yl = fsub<F, M>(T3, Bv);                                    // lane 0: Y3 = A - Bv < 2M (the other lanes' values are unused)
   p.x = X3;
-  p.y = fsub<F, M>(A, Bv);                                            // < 2M
+  p.y = quad_bcast<0>(Yl);
   p.zz = quad_bcast<2>(T3);
   p.zzz = quad_bcast<3>(T3);
 }
@@ -206,9 +210,10 @@ __device__ __forceinline__ void xyzz_add_quad_reg(XYZZ<F>& acc, const XYZZ<F>& q
   const F PPP = quad_bcast<0>(T3), Qv = quad_bcast<1>(T3);
   const F X3 = fsub<F, 2 * M>(fsub<F, M>(RR, PPP), F::dbl(Qv));       // < 4M
   const F T4 = F::mul(quad_pick<F>(role, R, S1, T2, T2), quad_pick<F>(role, fsub<F, 4 * M>(Qv, X3), PPP, PPP, PPP));  // A | Bv | - | ZZZ3
-  const F A = quad_bcast<0>(T4), Bv = quad_bcast<1>(T4);
+  const F Bv = quad_bcast<1>(T4);
+  const F Yl = fsub<F, M>(T4, Bv);                                    // lane 0: Y3 = A - Bv < 2M
   acc.x = X3;
-  acc.y = fsub<F, M>(A, Bv);                                          // < 2M
+  acc.y = quad_bcast<0>(Yl);
   acc.zz = quad_bcast<2>(T3);
   acc.zzz = quad_bcast<3>(T4);
 }

@@ -33,6 +33,8 @@ struct MsmOptions {
   int K = 0;          // entries per lane (0 = choose from resident lanes)
   int S = 0;          // sort: scalars per partition block (0 = choose)
   uint32_t lanes = 196608;  // resident lanes of the accumulate kernel (set by the backend)
+  int host_window_sums = 0;  // 1: the c points per window go to the host, which also runs the Horner over the bits (the
+                             // round-1 arrangement, kept for comparison: DESIGN.md section 4.6)
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -198,6 +200,7 @@ struct MsmEngine {
     MsmPlan plan;
     bool busy = false;
     bool empty = false;   // len == 0
+    bool host_bits = false;  // the slot's buffer holds c points per window (MsmOptions::host_window_sums)
     void* hraw = nullptr; // pinned host buffer for the device output
     size_t hcap = 0;
   };
@@ -338,11 +341,15 @@ struct MsmEngine {
       bk.template launch_pyr<FD>(pa, W, ntasks);
     }
     // the window sums (Horner over the c points of every window) complete the device part of the combine
-    XYZZ<FD>* d_wsum = (XYZZ<FD>*)need(rP[1], (size_t)W * sizeof(XYZZ<FD>));
-    bk.template launch_window_sums<FD>(d_out, d_wsum, W, p.c);
+    XYZZ<FD>* d_wsum = d_out;
+    S.host_bits = opt.host_window_sums != 0;
+    if (!S.host_bits) {
+      d_wsum = (XYZZ<FD>*)need(rP[1], (size_t)W * sizeof(XYZZ<FD>));
+      bk.template launch_window_sums<FD>(d_out, d_wsum, W, p.c);
+    }
     bk.stage_end(sl, ST_REDUCE);
 
-    const size_t bytes = (size_t)W * sizeof(XYZZ<FD>);
+    const size_t bytes = (size_t)W * (S.host_bits ? p.c : 1) * sizeof(XYZZ<FD>);
     if (bytes > S.hcap) {
       if (S.hraw) bk.free_host(S.hraw);
       S.hraw = bk.alloc_host(bytes);
@@ -455,9 +462,12 @@ struct MsmEngine {
     bk.d2h_wait(sl);
     const MsmPlan& p = S.plan;
     const XYZZ<FD>* raw = (const XYZZ<FD>*)S.hraw;
-    const size_t cnt = (size_t)p.W;
+    const size_t cnt = (size_t)p.W * (S.host_bits ? p.c : 1);
     std::vector<XYZZ<HF>> sums(cnt);
     for (size_t i = 0; i < cnt; i++) sums[i] = xyzz_to_host<FD>(raw[i]);
+    if (S.host_bits) {
+      for (int w = 0; w < p.W; w++) sums[w] = window_sum_body<HF>(sums.data() + (size_t)w * p.c, p.c);
+    }
     return combine_windows<HF>(sums.data(), p.W, p.c);
   }
 
