@@ -33,8 +33,9 @@ struct MsmOptions {
   int K = 0;          // entries per lane (0 = choose from resident lanes)
   int S = 0;          // sort: scalars per partition block (0 = choose)
   uint32_t lanes = 196608;  // resident lanes of the accumulate kernel (set by the backend)
-  int host_window_sums = 0;  // 1: the c points per window go to the host, which also runs the Horner over the bits (the
-                             // round-1 arrangement, kept for comparison: DESIGN.md section 4.6)
+  int host_window_sums = 0;  // where the Horner over the bit sums of a window runs: 0 = on the device unless the caller is
+                             // pipelining MSMs (see reduce_buckets), 1 = always on the host (the round-1 arrangement),
+                             // 2 = always on the device
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -342,7 +343,10 @@ struct MsmEngine {
     }
     // the window sums (Horner over the c points of every window) complete the device part of the combine
     XYZZ<FD>* d_wsum = d_out;
-    S.host_bits = opt.host_window_sums != 0;
+    // ... unless another MSM of this engine is in flight: then the caller is pipelining, the host tail of this MSM hides
+    // under the next MSM's GPU work, and a longer device tail would only delay that MSM's accumulation (measured, BLS12-381
+    // G1 2^20: device sums 3.60 ms blocking / 3.26 ms per pipelined step, host sums 3.74 / 3.04)
+    S.host_bits = opt.host_window_sums == 1 || (opt.host_window_sums == 0 && slots[sl ^ 1].busy);
     if (!S.host_bits) {
       d_wsum = (XYZZ<FD>*)need(rP[1], (size_t)W * sizeof(XYZZ<FD>));
       bk.template launch_window_sums<FD>(d_out, d_wsum, W, p.c);
