@@ -150,6 +150,21 @@ CTT_HD XYZZ<F> window_sum_body(const XYZZ<F>* ow, int c) {
   xyzz_add<F>(r, ow[c - 1]);
   return r;
 }
+// both Horners in one chain, for the c points per window as the bucket reduction leaves them (host_window_sums): the
+// doublings of the bit Horner are the doublings of the window Horner, W*c in total
+template <class F>
+static inline XYZZ<F> combine_windows_bits(const XYZZ<F>* o, int W, int c) {
+  XYZZ<F> r = XYZZ<F>::inf();
+  for (int w = W - 1; w >= 0; w--) {
+    const XYZZ<F>* ow = o + (size_t)w * c;
+    for (int l = c - 1; l >= 0; l--) {
+      r = xyzz_dbl<F>(r);
+      if (l <= c - 2) xyzz_add<F>(r, ow[l]);
+    }
+    xyzz_add<F>(r, ow[c - 1]);
+  }
+  return r;
+}
 template <class F>
 static inline XYZZ<F> combine_windows(const XYZZ<F>* s, int W, int c) {
   XYZZ<F> r = XYZZ<F>::inf();
@@ -469,9 +484,7 @@ struct MsmEngine {
     const size_t cnt = (size_t)p.W * (S.host_bits ? p.c : 1);
     std::vector<XYZZ<HF>> sums(cnt);
     for (size_t i = 0; i < cnt; i++) sums[i] = xyzz_to_host<FD>(raw[i]);
-    if (S.host_bits) {
-      for (int w = 0; w < p.W; w++) sums[w] = window_sum_body<HF>(sums.data() + (size_t)w * p.c, p.c);
-    }
+    if (S.host_bits) return combine_windows_bits<HF>(sums.data(), p.W, p.c);
     return combine_windows<HF>(sums.data(), p.W, p.c);
   }
 
