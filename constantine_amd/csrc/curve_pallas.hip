@@ -4,5 +4,10 @@
 #ifndef CTT_FPU_CHAIN
 #define CTT_FPU_CHAIN 8
 #endif  // CTT_FPU_CHAIN
+// waves per SIMD the accumulate kernel is compiled for: 4 (128 registers + 60 B of scratch) measured 1.5 - 5 % faster than
+// 3 (141 registers) for the 9-limb fields, same box (profiles/bench_r02_waves4.txt)
+#ifndef CTT_ACCUM_WAVES
+#define CTT_ACCUM_WAVES 4
+#endif
 #include "hip_backend.h"
 extern "C" const ctt::CurveOps* ctt_ops_pallas(void) { return ctt::CurveImpl<ctt::PallasEc>::ops(); }
