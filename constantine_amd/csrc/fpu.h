@@ -550,14 +550,23 @@ struct Fp2<FpU<UP>> {
   // Karatsuba on unreduced columns (3 limb products, 2 reductions) was tried: the six live operands plus two sets
   // of Montgomery quotients spill the accumulate kernel to scratch (G2 accumulate 8.7 -> 126 ms); two sums of
   // products it is.
+  // The negated / combined operands only feed products: they stay lazy (no carry propagation, FpU "lazy forms"); the
+  // column budget of a sum of two products with one lazy operand each is LAZY_ONE, of (lazy sum) x (lazy difference) < LAZY_BOTH.
+  static_assert(F::LAZY_BOTH, "Fp2 over this base field needs the 28-bit-limb column budget");
+  CTT_HD static F add_lazy(const F& a, const F& b) {
+    F r;
+#pragma unroll
+    for (int i = 0; i < F::NL; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+  }
   CTT_HD static Fp2 mul(const Fp2& a, const Fp2& b) {
-    F na1 = F::template sub<KNEG>(F::zero(), a.c1);
+    F na1 = F::template sub_lazy<KNEG - 1>(F::zero(), a.c1);   // KNEG*p - a1
     return {F::mul2(a.c0, b.c0, na1, b.c1), F::mul2(a.c0, b.c1, a.c1, b.c0)};
   }
   CTT_HD static Fp2 sqr(const Fp2& a) {
-    F s = F::add(a.c0, a.c1);
-    F d = F::template sub<KNEG>(a.c0, a.c1);
-    return {F::mul(s, d), F::mul(F::dbl(a.c0), a.c1)};   // (a0+a1)(a0-a1), 2 a0 a1: two products, two reductions
+    F s = add_lazy(a.c0, a.c1);
+    F d = F::template sub_lazy<KNEG - 1>(a.c0, a.c1);          // a0 - a1 + KNEG*p
+    return {F::mul(s, d), F::mul(add_lazy(a.c0, a.c0), a.c1)};   // (a0+a1)(a0-a1), 2 a0 a1: two products, two reductions
   }
   // a*b + c*d: two products (not fused further: four base sum-of-products)
   CTT_HD static Fp2 mul2(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return add(mul(a, b), mul(c, d)); }

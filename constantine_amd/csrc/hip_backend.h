@@ -38,7 +38,8 @@ __global__ void k_convert_points(const Affine<F>* in, void* out, uint32_t n) {
 #ifndef CTT_ACCUM_WAVES
 #define CTT_ACCUM_WAVES 2   // waves per SIMD the accumulate kernel is compiled for (register budget 512/waves)
 #endif
-// an XYZZ accumulator over Fp2 (448 bytes) plus a point and temporaries does not fit two waves per SIMD
+// an XYZZ accumulator over Fp2 (448 bytes) plus a point and the temporaries of the addition does not fit two waves per SIMD
+// (parking ZZ, ZZZ in LDS to get there was measured and rejected: DESIGN.md section 5)
 template <class F>
 __global__ void __launch_bounds__(ACCUM_BLOCK, (sizeof(XYZZ<F>) > 256 ? 1 : CTT_ACCUM_WAVES)) k_accum(AccumArgs<F> a) {
   accum_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
