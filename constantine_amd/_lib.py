@@ -28,7 +28,7 @@ def exported_symbols():
              "ctt_hip_msm_device", "ctt_hip_msm_device_submit", "ctt_hip_msm_device_finish", "ctt_hip_msm_sync", "ctt_hip_msm_bases_create", "ctt_hip_msm_bases_destroy",
              "ctt_hip_msm_with_bases", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
              "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream", "ctt_hip_msm_wait_stream",
-             "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min"]
+             "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min", "ctt_hip_subgroup_check"]
     return syms
 
 
@@ -101,5 +101,6 @@ def lib():
     L.ctt_hip_msm_set_devices.argtypes = [ctypes.POINTER(i32), i32]
     L.ctt_hip_msm_set_shard_min.argtypes = [sz]
     L.ctt_hip_msm_set_shard_min.restype = None
+    L.ctt_hip_subgroup_check.argtypes = [vp, i32, vp, vp, sz, i32]
     _lib = L
     return L

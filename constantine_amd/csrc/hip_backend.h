@@ -271,6 +271,11 @@ __global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t
   gen_point_body<typename C::F>(G, seed, first, n, out, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+template <class C>
+__global__ void __launch_bounds__(EC_BLOCK) k_subgroup_check(const Affine<typename C::F>* pts, uint32_t n, uint8_t* ok) {
+  subgroup_check_body<C>(pts, n, ok, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // probe of the device field FD (msm_bodies.h dev_field_probe): inputs in the reference representation, output = raw FD limbs
 template <class F, class FD>
 __global__ void k_field_op_dev(int op, const F* a, const F* b, FD* r, uint32_t n) {
@@ -513,6 +518,8 @@ struct CurveOps {
   // dst[i] = affine(src[i]) for n Jacobian (src_kind 1) or projective (2) points, device memory, K points per lane
   void (*batch_affine)(HipBackend* bk, int src_kind, void* d_dst, const void* d_src, uint32_t n, uint32_t K);
   size_t fe_bytes;  // one coordinate
+  // ok[j] = [r]P_j is the neutral element (r = the curve order), n points and n flags in device memory
+  void (*subgroup_check)(HipBackend* bk, const void* d_points, uint32_t n, void* d_ok);
 };
 
 template <class C>
@@ -615,8 +622,14 @@ struct CurveImpl {
     hipLaunchKernelGGL(k_batch_affine<F>, dim3((lanes + EC_BLOCK - 1) / EC_BLOCK), dim3(EC_BLOCK), 0, bk->stream, a);
     HIP_CHECK(hipGetLastError());
   }
+  static void subgroup_check(HipBackend* bk, const void* d_points, uint32_t n, void* d_ok) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_subgroup_check<C>, dim3((n + EC_BLOCK - 1) / EC_BLOCK), dim3(EC_BLOCK), 0, bk->stream,
+                       (const Affine<F>*)d_points, n, (uint8_t*)d_ok);
+    HIP_CHECK(hipGetLastError());
+  }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F)};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F), subgroup_check};
     return &o;
   }
 };

@@ -513,6 +513,26 @@ CTT_HD FD dev_field_probe(int op, const FD& x, const FD& y) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Subgroup check of many points at once: ok[j] = ([r]P_j is the neutral element), r = the curve order (the modulus of C::Fr).
+// What the reference's deserialisers do per point (e.g. ethereum_evm_precompiles.nim fromRawCoords -> isInSubgroup); here the
+// MSM's callers (EIP-2537 G1MSM/G2MSM, KZG commitments) validate all their points with one launch: the bits of r are the same
+// for every lane, so the double-and-add is convergent.
+// ---------------------------------------------------------------------------------------------
+template <class C>
+CTT_HD void subgroup_check_body(const Affine<typename C::F>* pts, uint32_t n, uint8_t* ok, uint32_t j) {
+  using F = typename C::F;
+  using Fr = typename C::Fr;
+  if (j >= n) return;
+  const Affine<F> P = pts[j];
+  XYZZ<F> r = XYZZ<F>::inf();
+  for (int i = 32 * Fr::N - 1; i >= 0; i--) {
+    r = xyzz_dbl<F>(r);
+    if ((Fr::Params::P[i >> 5] >> (i & 31)) & 1u) xyzz_madd<F>(r, P, false);
+  }
+  ok[j] = r.is_inf() ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic subgroup points for benchmarks/tests: P_i = [s_i]G, s_i = 128-bit splitmix word pair | 1
 // (same definition as oracle/pyoracle.py synth_point; mirrors the distribution of the reference's
 // bench inputs, benchmarks/bench_elliptic_parallel_template.nim:78-102)

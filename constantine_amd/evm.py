@@ -8,8 +8,8 @@ Input: pairs of (point, scalar); a G1 point is 64 B x | 64 B y (big-endian, top 
 point is x.c0 | x.c1 | y.c0 | y.c1; the scalar is 32 B big-endian, any value < 2^256 (reduced mod r here, as upstream).
 Points are checked to be on the curve and in the prime-order subgroup.  Output: the affine sum, same encoding.
 
-The curve checks run on the host in plain integer arithmetic; the subgroup check ([r]P = infinity) and the MSM itself
-run on the GPU through the Constantine-compatible C symbols.
+The curve checks run on the host in plain integer arithmetic; the subgroup checks ([r]P = infinity, all points in one
+launch: ctt_hip_subgroup_check) and the MSM itself (the Constantine-compatible C symbol) run on the GPU.
 """
 from enum import Enum
 
@@ -82,18 +82,20 @@ def _jac_to_affine(F2: bool, r: np.ndarray):
     return X * zi * zi % _P, Y * zi * zi * zi % _P
 
 
-def _subgroup_check(curve: str, pts: np.ndarray):
-    """[r]P == infinity for every (non-neutral) point, each as a one-pair MSM on the GPU."""
-    r_le = np.frombuffer(_R.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32)
-    seen = set()
-    for i in range(pts.shape[0]):
-        key = bytes(pts[i])
-        if key in seen or not any(key):
-            continue
-        seen.add(key)
-        out = multiScalarMul_vartime(curve, r_le, pts[i:i + 1], coord="jac")
-        if _jac_to_affine(curve.endswith("g2"), out) is not None:
-            raise EvmError(CttEVMStatus.cttEVM_PointNotInSubgroup)
+def _validate(curve: str, pts: np.ndarray, on_curve):
+    """The reference validates the pairs in order, each point fully (on the curve, then in the subgroup:
+    ethereum_evm_precompiles.nim fromRawCoords) before the next one: the status is that of the FIRST offending point.
+    The subgroup checks ([r]P = neutral) of all points run as one GPU launch."""
+    from .msm import subgroup_check
+    in_subgroup = subgroup_check(curve, pts) if all(on_curve) else None
+    for i, oc in enumerate(on_curve):
+        if not oc:
+            # an earlier point outside the subgroup comes first: check the points in front of this one
+            if i and not subgroup_check(curve, pts[:i]).all():
+                raise EvmError(CttEVMStatus.cttEVM_PointNotInSubgroup)
+            raise EvmError(CttEVMStatus.cttEVM_PointNotOnCurve)
+    if not in_subgroup.all():
+        raise EvmError(CttEVMStatus.cttEVM_PointNotInSubgroup)
 
 
 def _scalars(recs, off):
@@ -105,14 +107,13 @@ def eth_evm_bls12381_g1msm(inputs: bytes) -> bytes:
     if len(inputs) == 0 or len(inputs) % 160 != 0:
         raise EvmError(CttEVMStatus.cttEVM_InvalidInputSize)
     recs = [inputs[i:i + 160] for i in range(0, len(inputs), 160)]
-    rows = []
+    rows, on_curve = [], []
     for rec in recs:
         x, y = _fp(rec[0:64]), _fp(rec[64:128])
-        if not (x == 0 and y == 0) and (y * y - x * x * x - 4) % _P != 0:
-            raise EvmError(CttEVMStatus.cttEVM_PointNotOnCurve)
+        on_curve.append((x == 0 and y == 0) or (y * y - x * x * x - 4) % _P == 0)
         rows.append(_mont(x) + _mont(y))
     pts = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), 96)
-    _subgroup_check("bls12_381_g1", pts)
+    _validate("bls12_381_g1", pts, on_curve)
     res = _jac_to_affine(False, multiScalarMul_vartime("bls12_381_g1", _scalars(recs, 128), pts, coord="jac"))
     if res is None:
         return bytes(128)
@@ -123,18 +124,19 @@ def eth_evm_bls12381_g2msm(inputs: bytes) -> bytes:
     if len(inputs) == 0 or len(inputs) % 288 != 0:
         raise EvmError(CttEVMStatus.cttEVM_InvalidInputSize)
     recs = [inputs[i:i + 288] for i in range(0, len(inputs), 288)]
-    rows = []
+    rows, on_curve = [], []
     for rec in recs:
         x = (_fp(rec[0:64]), _fp(rec[64:128]))
         y = (_fp(rec[128:192]), _fp(rec[192:256]))
+        ok = True
         if not (x == (0, 0) and y == (0, 0)):
             x3 = _fp2_mul(_fp2_mul(x, x), x)
             y2 = _fp2_mul(y, y)
-            if ((y2[0] - x3[0] - 4) % _P, (y2[1] - x3[1] - 4) % _P) != (0, 0):   # b' = 4(1 + i)
-                raise EvmError(CttEVMStatus.cttEVM_PointNotOnCurve)
+            ok = ((y2[0] - x3[0] - 4) % _P, (y2[1] - x3[1] - 4) % _P) == (0, 0)   # b' = 4(1 + i)
+        on_curve.append(ok)
         rows.append(_mont(x[0]) + _mont(x[1]) + _mont(y[0]) + _mont(y[1]))
     pts = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), 192)
-    _subgroup_check("bls12_381_g2", pts)
+    _validate("bls12_381_g2", pts, on_curve)
     res = _jac_to_affine(True, multiScalarMul_vartime("bls12_381_g2", _scalars(recs, 256), pts, coord="jac"))
     if res is None:
         return bytes(256)

@@ -10,7 +10,8 @@ The commitment is the 4096-point BLS12-381 G1 MSM of the blob's field elements w
 bit-reversal order; the SRS is the textbook cached-base case, so it is uploaded and converted once
 (constantine_amd.CachedBases) and every commitment moves only 128 KiB of scalars.
 
-Only the commitment is implemented (the MSM caller); proofs, verification and cell/PeerDAS functions are out of scope.
+Commitments and opening proofs are implemented (the MSM callers: blob_to_kzg_commitment, compute_kzg_proof,
+compute_blob_kzg_proof); verification needs pairings and is out of scope, like the cell/PeerDAS functions.
 """
 from enum import Enum
 
@@ -105,6 +106,7 @@ class EthereumKZGContext:
         pts = _bit_reversal_permutation(pts)
         arr = np.frombuffer(b"".join(_aff_mont_bytes(P) for P in pts), dtype=np.uint8)
         self.srs_lagrange_brp_g1 = arr.reshape(FIELD_ELEMENTS_PER_BLOB, 96).copy()
+        self.hip_ctx = ctx   # ctt_hip_msm_ctx* (None = the process default context): the GPU everything of this context runs on
         self._bases = CachedBases("bls12_381_g1", self.srs_lagrange_brp_g1, ctx=ctx)
 
     @classmethod
@@ -234,15 +236,13 @@ def compute_kzg_proof(ctx: EthereumKZGContext, blob: bytes, z_bytes: bytes):
 
 
 def _subgroup_check_g1(ctx: EthereumKZGContext, P):
-    """[r]P == neutral, as a one-pair MSM on the GPU (the reference validates commitments the same way it validates
-    any deserialised point: on the curve and in the prime-order subgroup)."""
+    """[r]P == neutral on the GPU the context's SRS lives on (the reference validates commitments the same way it
+    validates any deserialised point: on the curve and in the prime-order subgroup)."""
     if P is None:
         return
-    from .msm import multiScalarMul_vartime
-    r_le = np.frombuffer(_R.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32)
+    from .msm import subgroup_check
     pt = np.frombuffer(_aff_mont_bytes(P), dtype=np.uint8).reshape(1, 96)
-    out = multiScalarMul_vartime("bls12_381_g1", r_le, pt, coord="jac")
-    if any(bytes(out[96:144])):
+    if not subgroup_check("bls12_381_g1", pt, ctx=ctx.hip_ctx)[0]:
         raise KzgError(cttEthKzgStatus.cttEthKzg_EccPointNotInSubGroup)
 
 

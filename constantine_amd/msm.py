@@ -191,6 +191,17 @@ def set_shard_min(pairs_per_device):
     _lib.lib().ctt_hip_msm_set_shard_min(int(pairs_per_device))
 
 
+def subgroup_check(curve, points, ctx=None):
+    """ok[i] = ([r]points[i] is the neutral element), r = the curve order, for all points in one launch
+    (ctt_hip_subgroup_check; the reference checks deserialised points one by one: isInSubgroup)."""
+    info = CURVES[curve]
+    pts = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, info.aff_bytes)
+    ok = np.zeros(pts.shape[0], dtype=np.uint8)
+    if _lib.lib().ctt_hip_subgroup_check(ctx, info.cid, _ptr(ok), _ptr(pts), pts.shape[0], 0) != 0:
+        raise RuntimeError("ctt_hip_subgroup_check failed")
+    return ok.astype(bool)
+
+
 def ec_sum_affine(curve, pts_aff, coord="aff"):
     """Host-only sum of affine points (combining per-GPU partial MSMs)."""
     info = CURVES[curve]

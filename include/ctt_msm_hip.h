@@ -202,6 +202,10 @@ int ctt_hip_sum_reduce(ctt_hip_msm_ctx* ctx, int curve, int out_kind, void* r, c
  * batchAffine(_vartime) (ec_shortweierstrass_batch_ops.nim:44-345).  Both arrays on the host (on_device = 0) or both
  * in HBM (1).  Blocking. */
 int ctt_hip_batch_affine(ctt_hip_msm_ctx* ctx, int curve, int src_kind, void* dst, const void* src, size_t n, int on_device);
+/* ok[i] = 1 when [r]points[i] is the neutral element (r = the curve order): the subgroup check that the MSM's callers run
+ * on deserialised points (eth_evm_bls12381_g1msm / g2msm, ethereum_evm_precompiles.nim:894-975; KZG commitments), for all n
+ * points in one launch.  points: affine, host (points_on_device = 0) or device memory; ok: n bytes of host memory. */
+int ctt_hip_subgroup_check(ctt_hip_msm_ctx* ctx, int curve, uint8_t* ok, const void* points, size_t n, int points_on_device);
 /* the engine's hipStream_t */
 void* ctt_hip_msm_stream(ctt_hip_msm_ctx* ctx);
 

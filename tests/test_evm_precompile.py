@@ -44,3 +44,29 @@ def test_precompile_vectors_on_gpu(group):
             fn(bytes.fromhex(inp))
         if "subgroup" in err:
             assert e.value.status == evm.CttEVMStatus.cttEVM_PointNotInSubgroup, name
+
+
+@pytest.mark.gpu
+def test_status_is_that_of_the_first_offending_point():
+    """The reference validates pair by pair (fromRawCoords: on the curve, then in the subgroup): with several bad points the
+    status is the first one's.  All subgroup checks of a call run as one GPU launch (ctt_hip_subgroup_check)."""
+    from constantine_amd import evm
+    from constantine_amd.msm import subgroup_check
+    from oracle import cref
+    sub = next(inp for _, inp, err in DOC["g1_fail"] if "subgroup" in err)
+    off_subgroup = bytes.fromhex(sub)[:128]                      # on the curve, outside the subgroup
+    off_curve = (1).to_bytes(64, "big") + (1).to_bytes(64, "big")
+    good = bytes.fromhex(DOC["g1"][0][1])[:128]
+    k = (5).to_bytes(32, "big")
+    for pts, want in (((off_subgroup, off_curve), "cttEVM_PointNotInSubgroup"),
+                      ((good, off_curve, off_subgroup), "cttEVM_PointNotOnCurve"),
+                      ((good, good, off_subgroup, off_curve), "cttEVM_PointNotInSubgroup"),
+                      ((off_curve, off_subgroup), "cttEVM_PointNotOnCurve")):
+        with pytest.raises(evm.EvmError) as e:
+            evm.eth_evm_bls12381_g1msm(b"".join(p + k for p in pts))
+        assert e.value.status.name == want
+    # the batched check itself, all six curves: subgroup points pass, the neutral passes
+    for name in cref.AFF_BYTES:
+        pts = cref.gen_points(name, 3, 65)
+        pts[7] = 0
+        assert subgroup_check(name, pts).all(), name
