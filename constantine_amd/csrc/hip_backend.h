@@ -375,21 +375,6 @@ struct HipBackend {
     HIP_CHECK(hipEventRecord(ev_copy, cpy));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_copy, 0));
   }
-  // Side work of a lone MSM on the copy stream (the point conversion underneath the sort): side_begin orders the copy
-  // stream after what the main stream holds now and redirects launch_convert there, side_end records its completion,
-  // side_join makes the main stream wait for it.
-  hipEvent_t ev_side_fork = nullptr, ev_side_done = nullptr;
-  bool on_side = false;
-  void side_begin() {
-    HIP_CHECK(hipEventRecord(ev_side_fork, stream));
-    HIP_CHECK(hipStreamWaitEvent(cpy, ev_side_fork, 0));
-    on_side = true;
-  }
-  void side_end() {
-    HIP_CHECK(hipEventRecord(ev_side_done, cpy));
-    on_side = false;
-  }
-  void side_join() { HIP_CHECK(hipStreamWaitEvent(stream, ev_side_done, 0)); }
   void d2h_async(int slot, void* dst_pinned, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst_pinned, src, b, hipMemcpyDeviceToHost, cur()));
     HIP_CHECK(hipEventRecord(ev_done[slot], cur()));
@@ -450,7 +435,7 @@ struct HipBackend {
   }
   template <class F, class FD>
   void launch_convert(const Affine<F>* in, void* out, uint32_t n) {
-    hipLaunchKernelGGL((k_convert_points<F, FD>), grid1(n, 256), dim3(256), 0, on_side ? cpy : stream, in, out, n);
+    hipLaunchKernelGGL((k_convert_points<F, FD>), grid1(n, 256), dim3(256), 0, stream, in, out, n);
     HIP_CHECK(hipGetLastError());
   }
   void launch_digits_sort(const SortArgs& a);  // msm_engine.hip

@@ -256,7 +256,6 @@ struct MsmEngine {
   Staged accumulate_pairs(int sl, const MsmPlan& p, const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in,
                           const void* d_prepared, void* d_converted, XYZZ<FD>* d_buckets) {
     const uint32_t n = p.n, W = p.W, B = p.B;
-    bool side_convert = false;
     bk.stage_begin(sl, ST_DIGITS);
     const uint32_t* d_scalars = d_coefs;
     if (coef_is_fr) {
@@ -270,13 +269,7 @@ struct MsmEngine {
       if (d_prepared) {
         d_points = d_prepared;
       } else {
-        // a lone MSM (nothing else of this engine in flight) converts its points on the side stream, underneath the sort:
-        // the conversion is HBM-bound, the sort LDS-bound.  With MSMs in flight the GPU is busy anyway and the copy of
-        // the kernel list stays in one stream.
-        side_convert = !slots[sl ^ 1].busy;
-        if (side_convert) bk.side_begin();
         bk.template launch_convert<F, FD>(d_points_in, d_converted, n);
-        if (side_convert) bk.side_end();
         d_points = d_converted;
       }
       point_stride = gather_stride<FD>();
@@ -313,7 +306,6 @@ struct MsmEngine {
     // wave slot of the chip for its whole duration, and a tail kernel enqueued behind it would wait it out (measured on
     // a slower box: reduce span 2.4 ms, the pipeline slower than the serial order).  Worst case this is the serial order.
     bk.tail_wait();
-    if (side_convert) bk.side_join();
     bk.stage_begin(sl, ST_ACCUM);
     st.d_buckets = d_buckets;
     bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));

@@ -28,9 +28,6 @@ struct EmuBackend {
   void d2h_sync(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void h2d(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void h2d_done() {}
-  void side_begin() {}
-  void side_end() {}
-  void side_join() {}
   template <class F>
   void launch_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
     for (uint32_t i = 0; i < set_elems; i++) bucket_sum_body<F>(sets, nsets, set_elems, i);
