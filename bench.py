@@ -36,12 +36,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-# v_mad_u64_u32 per mixed addition of the accumulate kernel: 8 products + 2 squares + 9 Montgomery reductions on NL
-# carry-free limbs = 8 NL^2 + NL (NL + 1) + 9 NL^2 (NL = 14 for BLS12-381, 9 for the 254/255-bit fields); DESIGN.md 4.3.
+# v_mad_u64_u32 per mixed addition of the accumulate kernel, as executed (ISA count of the hot path):
+# 8 products + 2 squares + 9 Montgomery reductions on NL carry-free limbs = 8 NL^2 + NL (NL + 1) + 9 NL^2 (NL = 14 for
+# BLS12-381, 9 for BN254); the Pasta primes have three zero limbs and p_0 = 1, which drop products: 1224.
 # G2: the same formula over Fp2 -- a product is 4 base products + 2 reductions, a square 2 + 2.
-MADS_PER_MIXED_ADD = {"bls12_381_g1": 3542, "bn254_snarks_g1": 1467, "pallas": 1467, "vesta": 1467,
+MADS_PER_MIXED_ADD = {"bls12_381_g1": 3542, "bn254_snarks_g1": 1467, "pallas": 1224, "vesta": 1224,
                       "bls12_381_g2": 8 * (4 * 196 + 2 * 196) + 2 * (2 * 196 + 2 * 196)}
-INT_MAD_PEAK = 31.0e12         # v_mad_u64_u32 lane-ops/s, measured on MI355X (profiles/microbench_fpu_r01.jsonl: 79.2 G products/s x 393)
+# v_mad_u64_u32 lane-ops/s of the whole chip: profiles/microbench_isa_r02.jsonl (tools/microbench_isa.hip: one asm block of 32
+# instructions per loop body, 8 waves per SIMD; 33.3 T at 2 waves per SIMD).  Round 1 used 31 T, taken from its multiplier chain.
+INT_MAD_PEAK = 34.5e12
+INT_MAD_PEAK_R01 = 31.0e12
 BYTES_PER_PAIR = {"bls12_381_g1": 128, "bn254_snarks_g1": 96, "pallas": 96, "vesta": 96, "bls12_381_g2": 224}
 BASELINE_CONFIG = {("bls12_381_g1", 20, 1): "configs[1]", ("bn254_snarks_g1", 22, 1): "configs[2]",
                    ("bls12_381_g2", 20, 1): "configs[4]", ("pallas", 20, 1): "configs[4]", ("vesta", 20, 1): "configs[4]"}
@@ -249,6 +253,10 @@ def main():
             out["roofline"]["int_mad"] = {
                 "instr": "v_mad_u64_u32", "per_launch": mads, "achieved": mads / t_acc / 1e12, "peak": INT_MAD_PEAK / 1e12,
                 "unit": "T lane-ops/s", "frac": mads / t_acc / INT_MAD_PEAK,
+                "frac_vs_round1_peak_31T": mads / t_acc / INT_MAD_PEAK_R01,
+                "note": "the multiply-adds are ~78 % of the kernel's VALU instructions; every VOP3 instruction issues at the same "
+                        "~4.5 cycles per wave (profiles/microbench_isa_r02.jsonl), so the kernel's own roof is its instruction "
+                        "count: profiles/pmc_r02_sq_counters_k_accum_*.txt put it at 94 % of the VALU issue slots",
             }
 
     # ---- the reference bench's own definition: one blocking call per iteration ----------------------------
