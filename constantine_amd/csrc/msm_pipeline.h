@@ -42,12 +42,15 @@ struct MsmOptions {
 // (ec_multi_scalar_mul_scheduler.nim:172-223) models a CPU; any c yields the same group element, so the device
 // uses its own cost model with constants measured on MI355X for BLS12-381 (profiles/): they only rank the
 // candidates, so the same model serves the other curves.
-//   accumulate  W*N mixed adds at 0.155 ns each (2.6 ms / 2^24 at full occupancy)
-//   reduce      c-1 passes, each at least one EC-add latency (17 us), plus 2*2^(c-1)*W adds of work
-//   merge       55 us + one 21 us tree step per doubling of the longest head chain.  The top window only has
+//   accumulate  W*N mixed adds at 0.142 ns each (2.38 ms / 2^24 at full occupancy)
+//   reduce      c-1 passes of 12 us latency each, plus 2*2^(c-1)*W adds of work at 0.24 ns (fitted to 0.43 ms at c = 16,
+//               0.185 ms at c = 13)
+//   merge       45 us + one 28 us tree step per doubling of the longest head chain.  The top window only has
 //               bits - (W-1)*c significant bits: when that is small its few buckets each receive N/2^(top-1)
 //               entries and the chain is long -- the model steers away from such c (e.g. c = 14 at N = 2^18)
 //   sort        0.02 ns per (window, pair) + 60 us
+// Round-2 check against measurements (BLS12-381 G1, ms per pipelined step): 2^16 c = 13 0.709 / c = 16 0.756; 2^18 c = 16
+// 1.22 / c = 13 1.59; the round-1 constants still chose c = 13 at 2^17, where c = 16 is the faster plan.
 static inline uint32_t plan_entries_per_lane(uint32_t n, int W, uint32_t lanes) {
   uint64_t total = (uint64_t)W * n;
   uint32_t K = (uint32_t)((total + lanes - 1) / lanes);
@@ -62,8 +65,8 @@ static inline int choose_window_bits(uint32_t n, int bits, uint32_t lanes) {
     const int W = bits / c + 1;
     const double B = (double)(1u << (c - 1));
     const double K = (double)plan_entries_per_lane(n, W, lanes);
-    const double acc = (double)W * n * 0.155e-3;
-    const double red = (c - 1) * 17.0 + 2.0 * B * W * 0.25e-3;
+    const double acc = (double)W * n * 0.142e-3;
+    const double red = (c - 1) * 12.0 + 2.0 * B * W * 0.24e-3;
     const int top = bits - (W - 1) * c;  // 0: the extra window only carries the Booth carry bit
     const double top_buckets = top > 1 ? (double)(1u << (top - 1)) : 1.0;
     double maxcnt = (double)n / top_buckets;
@@ -71,7 +74,7 @@ static inline int choose_window_bits(uint32_t n, int bits, uint32_t lanes) {
     double chain = maxcnt / K;
     int steps = 0;
     while (chain > 1.0) { chain *= 0.5; steps++; }
-    const double mer = 55.0 + 21.0 * steps;
+    const double mer = 45.0 + 28.0 * steps;
     const double srt = (double)W * n * 0.02e-3 + 60.0;
     const double cost = acc + red + mer + srt;
     if (cost < best) { best = cost; bc = c; }
@@ -253,6 +256,23 @@ struct MsmEngine {
     uint32_t* d_hkey;
     uint32_t* d_tkey;
   };
+  // the grow-only workspace of stage 1 sized for plan p up front (need() frees and reallocates -- a device-wide
+  // synchronisation -- when a later, larger slice of a host-pointer MSM asks for more)
+  void reserve_stage1(const MsmPlan& p, bool coef_is_fr) {
+    const size_t W = p.W, n = p.n;
+    if (coef_is_fr) need(scal, n * 32);
+    need(part, W * n * 4);
+    need(counts, (size_t)p.S * W * p.NG * 4);
+    need(totals, W * p.NG * 4);
+    need(gbase, W * (p.NG + 1) * 4);
+    need(bstart, W * (p.B + 1) * 4);
+    need(entries, W * n * 4);
+    need(maxcount, 256);
+    need(heads, W * p.G * sizeof(XYZZ<FD>));
+    need(tails, W * p.G * sizeof(XYZZ<FD>));
+    need(hkey, W * p.G * 4);
+    need(tkey, W * p.G * 4);
+  }
   Staged accumulate_pairs(int sl, const MsmPlan& p, const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in,
                           const void* d_prepared, void* d_converted, XYZZ<FD>* d_buckets) {
     const uint32_t n = p.n, W = p.W, B = p.B;
@@ -432,20 +452,41 @@ struct MsmEngine {
     const int sl = claim_slot(n);
     if (sl < 0 || n == 0) return sl;
     const uint32_t nch = host_chunks(n, want_chunks);
-    const uint32_t base = n / nch, cutoff = n % nch;   // balanced slices (partitioners.nim:44-77)
+    // Growing slices: only the first slice's upload is exposed, and slice i+1 may be as much larger than slice i as the
+    // GPU takes longer over a pair than the PCIe link does (accumulate + sort ~3.3 ms against 2.4 ms of copy for 2^20
+    // BLS12-381 pairs) -- weights 1, 1.4, 1.96, ...; every slice a multiple of 64 pairs except the last.
+    std::vector<uint32_t> bound(nch + 1, 0);
+    {
+      double wsum = 0, w = 1;
+      for (uint32_t i = 0; i < nch; i++, w *= 1.4) wsum += w;
+      double acc = 0;
+      w = 1;
+      for (uint32_t i = 0; i + 1 < nch; i++, w *= 1.4) {
+        acc += w;
+        uint64_t b = (uint64_t)((double)n * acc / wsum);
+        b &= ~63ull;
+        if (b <= bound[i]) b = bound[i] + 1;     // tiny inputs: at least one pair per slice
+        if (b > n - (nch - 1 - i)) b = n - (nch - 1 - i);
+        bound[i + 1] = (uint32_t)b;
+      }
+      bound[nch] = n;
+    }
+    uint32_t largest = 0;
+    for (uint32_t i = 0; i < nch; i++) largest = bound[i + 1] - bound[i] > largest ? bound[i + 1] - bound[i] : largest;
     MsmOptions o = opt;
     if (o.c <= 0) o.c = choose_window_bits(n, C::BITS, o.lanes);  // one window size for the whole MSM
     bk.stage_begin(sl, ST_TOTAL);
-    const MsmPlan p0 = make_plan(base + (cutoff ? 1 : 0), C::BITS, o);   // the largest slice sizes the workspace
+    const MsmPlan p0 = make_plan(largest, C::BITS, o);   // the largest slice sizes the workspace
     const size_t set = (size_t)p0.W * p0.B;
     XYZZ<FD>* d_sets = (XYZZ<FD>*)need(buckets, (size_t)nch * set * sizeof(XYZZ<FD>));
     void* d_conv_all = nullptr;
     if constexpr (kConvert) d_conv_all = need(cpoints, (size_t)n * gather_stride<FD>());
+    reserve_stage1(p0, coef_is_fr);
     MsmPlan plast = p0;
     Staged st_prev{};
     MsmPlan p_prev = p0;
     for (uint32_t i = 0; i < nch; i++) {
-      const uint32_t start = i * base + (i < cutoff ? i : cutoff), cnt = base + (i < cutoff ? 1 : 0);
+      const uint32_t start = bound[i], cnt = bound[i + 1] - bound[i];
       uint32_t* d_c = (uint32_t*)d_stage_coefs + (size_t)start * 8;
       Affine<F>* d_p = (Affine<F>*)d_stage_points + start;
       bk.h2d(d_c, (const char*)h_coefs + (size_t)start * 32, (size_t)cnt * 32);                   // the GPU works on slice i-1 meanwhile
