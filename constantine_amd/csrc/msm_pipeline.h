@@ -438,11 +438,11 @@ struct MsmEngine {
   // reduction.  d_stage_coefs / d_stage_points: device staging for all n pairs (caller-owned).  Blocking on the copies,
   // asynchronous from the last accumulation on; returns the slot, or -1 when both slots are in flight.
   static uint32_t host_chunks(uint32_t n, int want) {
-    // automatic (measured, profiles/hostptr_r02.txt: BLS12-381 G1, ms per call with 1 / 2 / 3 / 4 slices -- 2^18: 2.40 /
-    // 2.37 / 2.56 / 2.77, 2^20: 6.43 / 5.43 / 5.19 / 5.01, 2^22: 22.8 / 18.0 / 16.5 / 15.7): only the first slice's upload
-    // is exposed, every extra slice costs one more sort launch sequence and one more addition per bucket.
+    // automatic (measured, profiles/hostptr_r02.txt: BLS12-381 G1, ms per call with 1 slice / 4 slices -- 2^16: 1.22 / 1.85,
+    // 2^18: 2.31 / 2.79 (2 slices: 2.35), 2^20: 6.37 / 5.05, 2^22: 22.8 / 15.4): only the first slice's upload is exposed,
+    // every extra slice costs one more sort launch sequence and one more addition per bucket.
     // An explicit request is honoured.
-    uint32_t cch = want > 0 ? (uint32_t)want : (n >= (3u << 18) ? 4u : n >= (3u << 16) ? 2u : 1u);
+    uint32_t cch = want > 0 ? (uint32_t)want : (n >= (3u << 18) ? 4u : n >= (3u << 17) ? 2u : 1u);
     if (cch > 8) cch = 8;
     if (cch > n) cch = n;
     return cch < 1 ? 1 : cch;
