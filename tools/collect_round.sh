@@ -55,7 +55,7 @@ timeout 300 python bench.py --curve bn254_snarks_g1 --log2n 22 --steps 20 --warm
 timeout 300 python bench.py --curve pallas --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_pallas.json" 2>> "$OUT/bench.err"
 timeout 300 python bench.py --curve vesta --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_vesta.json" 2>> "$OUT/bench.err"
 timeout 300 python bench.py --curve bls12_381_g2 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g2.json" 2>> "$OUT/bench.err"
-for k in 16 18 22 24; do
+for k in 16 17 18 19 22 24; do
   timeout 300 python bench.py --log2n $k --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g1_2pow$k.json" 2>> "$OUT/bench.err"
 done
 timeout 300 python tools/bench_batch_ops.py > "$OUT/batch_ops_$TAG.txt" 2>> "$OUT/bench.err"
