@@ -141,9 +141,8 @@ struct AccumArgs {
   uint32_t N, B, K, G;
 };
 
-// Z: where the accumulator's ZZ, ZZZ live between the additions (ec.h ZInRegs)
-template <class F, class Z>
-CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
+template <class F>
+CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
   if (g >= a.G) return;
   const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
   const uint64_t slot = (uint64_t)w * a.G + g;
@@ -166,29 +165,19 @@ CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
   uint32_t b = lo;
   uint32_t bend = bs[b + 1];
   bool first_run = true;
-  // the accumulator's "neutral" state lives in a flag (xyzz_madd_core): nothing to zero when a run is flushed
-  F X, Y;
+  // the accumulator's "neutral" state lives in a flag (xyzz_madd_flag): nothing to zero when a run is flushed
+  XYZZ<F> acc;
   bool empty = true;
-  auto current = [&]() {
-    XYZZ<F> r;
-    if (empty) {
-      r = XYZZ<F>::inf();
-    } else {
-      r.x = X;
-      r.y = Y;
-      z.get(r.zz, r.zzz);
-    }
-    return r;
-  };
   const uint32_t* ent = a.entries + (uint64_t)w * a.N;
   for (uint32_t pos = p0; pos < p1; pos++) {
     if (pos == bend) {
       // bucket b is finished inside this lane's range
+      if (empty) acc = XYZZ<F>::inf();
       if (first_run && bs[b] < p0) {
-        a.heads[slot] = current();
+        a.heads[slot] = acc;
         hk = b;
       } else {
-        a.buckets[(uint64_t)w * a.B + b] = current();
+        a.buckets[(uint64_t)w * a.B + b] = acc;
       }
       first_run = false;
       empty = true;
@@ -201,26 +190,22 @@ CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
     Affine<F> pt = *(const Affine<F>*)rec;
     bool qinf;   // carry-free fields: the record's flag word (convert_point_body); reference layout: test x and y
     if constexpr (F::UNSAT) qinf = *(const uint32_t*)(rec + gather_flag_offset<F>()) != 0u; else qinf = pt.is_inf();
-    if (!qinf) xyzz_madd_core<F, Z>(X, Y, z, empty, pt.x, pt.y, (e >> 31) != 0);
+    if (!qinf) xyzz_madd_flag<F>(acc, empty, pt.x, pt.y, (e >> 31) != 0);
   }
+  if (empty) acc = XYZZ<F>::inf();
   const bool started_before = first_run && bs[b] < p0;
   const bool ends_after = bend > p1;
   if (started_before) {
-    a.heads[slot] = current();
+    a.heads[slot] = acc;
     hk = b;
   } else if (ends_after) {
-    a.tails[slot] = current();
+    a.tails[slot] = acc;
     tk = b;
   } else {
-    a.buckets[(uint64_t)w * a.B + b] = current();
+    a.buckets[(uint64_t)w * a.B + b] = acc;
   }
   a.hkey[slot] = hk;
   a.tkey[slot] = tk;
-}
-template <class F>
-CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
-  ZInRegs<F> z;
-  accum_body_z<F, ZInRegs<F>>(a, w, g, z);
 }
 
 // ---------------------------------------------------------------------------------------------
