@@ -142,7 +142,7 @@ struct AccumArgs {
 };
 
 template <class F>
-CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
+CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
   if (g >= a.G) return;
   const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
   const uint64_t slot = (uint64_t)w * a.G + g;
@@ -206,6 +206,92 @@ CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
   }
   a.hkey[slot] = hk;
   a.tkey[slot] = tk;
+}
+
+// the accumulate body in the X, Y + ZZ/ZZZ-holder form (ec.h xyzz_madd_core): used for the quadratic-extension fields
+template <class F, class Z>
+CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
+  if (g >= a.G) return;
+  const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
+  const uint64_t slot = (uint64_t)w * a.G + g;
+  const uint32_t nw = bs[a.B];
+  const uint64_t p0l = (uint64_t)g * a.K;
+  uint32_t hk = KEY_NONE, tk = KEY_NONE;
+  if (p0l >= nw) {
+    a.hkey[slot] = hk;
+    a.tkey[slot] = tk;
+    return;
+  }
+  const uint32_t p0 = (uint32_t)p0l;
+  const uint32_t p1 = (p0l + a.K < nw) ? p0 + a.K : nw;
+  // bucket containing position p0: bs[lo] <= p0 < bs[hi]
+  uint32_t lo = 0, hi = a.B;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (bs[mid] <= p0) lo = mid; else hi = mid;
+  }
+  uint32_t b = lo;
+  uint32_t bend = bs[b + 1];
+  bool first_run = true;
+  // the accumulator's "neutral" state lives in a flag (xyzz_madd_core): nothing to zero when a run is flushed
+  F X, Y;
+  bool empty = true;
+  auto current = [&]() {
+    XYZZ<F> r;
+    if (empty) {
+      r = XYZZ<F>::inf();
+    } else {
+      r.x = X;
+      r.y = Y;
+      z.get(r.zz, r.zzz);
+    }
+    return r;
+  };
+  const uint32_t* ent = a.entries + (uint64_t)w * a.N;
+  for (uint32_t pos = p0; pos < p1; pos++) {
+    if (pos == bend) {
+      // bucket b is finished inside this lane's range
+      if (first_run && bs[b] < p0) {
+        a.heads[slot] = current();
+        hk = b;
+      } else {
+        a.buckets[(uint64_t)w * a.B + b] = current();
+      }
+      first_run = false;
+      empty = true;
+      b++;
+      while (bs[b + 1] == pos) b++;  // skip empty buckets; terminates because pos < nw
+      bend = bs[b + 1];
+    }
+    uint32_t e = ent[pos];
+    const char* rec = (const char*)__builtin_assume_aligned((const char*)a.points + (uint64_t)(e & 0x7fffffffu) * a.point_stride, 16);
+    Affine<F> pt = *(const Affine<F>*)rec;
+    bool qinf;   // carry-free fields: the record's flag word (convert_point_body); reference layout: test x and y
+    if constexpr (F::UNSAT) qinf = *(const uint32_t*)(rec + gather_flag_offset<F>()) != 0u; else qinf = pt.is_inf();
+    if (!qinf) xyzz_madd_core<F, Z>(X, Y, z, empty, pt.x, pt.y, (e >> 31) != 0);
+  }
+  const bool started_before = first_run && bs[b] < p0;
+  const bool ends_after = bend > p1;
+  if (started_before) {
+    a.heads[slot] = current();
+    hk = b;
+  } else if (ends_after) {
+    a.tails[slot] = current();
+    tk = b;
+  } else {
+    a.buckets[(uint64_t)w * a.B + b] = current();
+  }
+  a.hkey[slot] = hk;
+  a.tkey[slot] = tk;
+}
+template <class F>
+CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
+  if constexpr (IsFp2<F>::value && F::UNSAT) {
+    ZInRegs<F> z;
+    accum_body_z<F, ZInRegs<F>>(a, w, g, z);
+  } else {
+    accum_body_xyzz<F>(a, w, g);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
