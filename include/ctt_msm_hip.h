@@ -142,8 +142,10 @@ int ctt_hip_msm_abi_version(void);
  * context on device $CTT_HIP_DEVICE (default 0). */
 ctt_hip_msm_ctx* ctt_hip_msm_ctx_create(int device);
 void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
-/* key in {"c","K","S"}: window bits, sorted entries per accumulate lane, scalars per sort-partition workgroup;
- * value 0 = automatic. Returns 0, or -1 for an unknown key. */
+/* key: "c" window bits, "K" sorted entries per accumulate lane, "S" scalars per sort-partition workgroup, "chunks" slices a
+ * host-pointer call is uploaded in (the upload of slice i+1 runs underneath the accumulation of slice i),
+ * "host_window_sums" where the Horner over a window's bit sums runs (0 automatic: on the device unless the caller keeps MSMs
+ * in flight, 1 host, 2 device).  value 0 = automatic.  Returns 0, or -1 for an unknown key. */
 int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
 /* r (HOST memory, `out_kind` layout) = sum coefs[i] * points[i]; d_coefs / d_points are DEVICE pointers
  * (BigInt canonical or Fr Montgomery 32-byte scalars; affine Montgomery points, C-API struct layout).
@@ -162,7 +164,8 @@ int ctt_hip_msm_device_finish(ctt_hip_msm_ctx* ctx, int ticket, int out_kind, vo
 void ctt_hip_msm_sync(ctt_hip_msm_ctx* ctx);
 /* Stream ordering: the engine's streams are not ordered against the caller's.  When device inputs may still be in
  * flight on `producer` (a hipStream_t), call this first: what the engine enqueues afterwards waits for the work
- * `producer` holds now.  Device outputs (ctt_hip_batch_affine on device arrays) are complete when their call returns. */
+ * `producer` holds now (a stream of the context's own device).  Device outputs (ctt_hip_batch_affine on device arrays) are
+ * complete when their call returns. */
 int ctt_hip_msm_wait_stream(ctt_hip_msm_ctx* ctx, void* producer);
 /* Multi-GPU: the host-pointer symbols of Part 1 shard a call by points over these devices -- the reference's msm-level
  * split (ec_multi_scalar_mul_parallel.nim:386-431; balanced chunks, threadpool/partitioners.nim:44-77) with GPUs for
@@ -176,7 +179,8 @@ void ctt_hip_msm_set_shard_min(size_t pairs_per_device);
  * msm_with_cached_base): base points are uploaded and converted to the device representation once and stay resident
  * in HBM; later MSMs move only the 32-byte coefficients. `points` / `coefs` are host pointers when the
  * *_on_device flag is 0, device pointers when it is 1. ctt_hip_msm_with_bases uses the first `len` bases and must be
- * called with the context the bases were created on (-1 otherwise: the records live on that context's GPU). */
+ * called with the context the bases were created on (-1 otherwise: the records live on that context's GPU); destroy the
+ * bases before their context. */
 typedef struct ctt_hip_msm_bases ctt_hip_msm_bases;
 ctt_hip_msm_bases* ctt_hip_msm_bases_create(ctt_hip_msm_ctx* ctx, int curve, const void* points, size_t len,
                                             int points_on_device);
