@@ -256,22 +256,14 @@ __global__ void __launch_bounds__(EC_BLOCK) k_pyr_quad(PyrArgs<F> a, uint32_t nt
   }
   xyzz_add_quad<F>(s1, s2, d1, d2, role);
 }
-// head-merge tree step (radix 4) with four lanes per addition: the running sum stays in registers over the up to three
-// additions of a step
+// head-merge tree step with four lanes per addition (a step has at most G / 2d additions per window)
 template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_merge_step_quad(MergeArgs<F> a, uint32_t d) {
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t g = lane >> 2;
-  const int role = (int)(lane & 3u);
-  const uint32_t np = merge_step_partners<F>(a, blockIdx.y, g, d);
-  if (np == 0) return;  // whole quads leave together
+  if (!merge_step_active<F>(a, blockIdx.y, g, d)) return;
   XYZZ<F>* h = a.heads + (uint64_t)blockIdx.y * a.G + g;
-  XYZZ<F> x = *h;
-  for (uint32_t j = 1; j <= np; j++) {
-    const XYZZ<F> y = h[(uint64_t)j * d];
-    xyzz_add_quad_reg<F>(x, y, role);
-  }
-  if (role == 0) *h = x;
+  xyzz_add_quad<F>(h, h + d, h, (XYZZ<F>*)nullptr, (int)(lane & 3u));
 }
 template <class C>
 __global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t first, uint32_t n, Affine<typename C::F>* out) {

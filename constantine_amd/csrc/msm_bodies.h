@@ -323,38 +323,30 @@ CTT_HD void merge_tail_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, bool 
   if (final_) a.buckets[(uint64_t)w * a.B + b] = r; else a.heads[slot + 1] = r;
 }
 
-// Tree step over the chain of heads of one bucket, radix 4: heads[g] += heads[g+d] + heads[g+2d] + heads[g+3d] (those that
-// exist) for g - chain_start = 0 mod 4d; the steps run d = 1, 4, 16, ...  Returns how many of the three partners lane g adds
-// in this step (0: nothing to do).  Two levels of the binary tree per launch: the steps are launch-latency bound except the
-// first, and a chain of m heads needs ceil(log4 m) of them.
+// tree step over the chain of heads of one bucket: heads[g] += heads[g+d] for g-chain_start = 0 mod 2d
+// (true when lane g has an addition to do in this step)
 template <class F>
-CTT_HD uint32_t merge_step_partners(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint32_t d) {
-  if (g >= a.G) return 0;
+CTT_HD bool merge_step_active(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint32_t d) {
+  if (g >= a.G) return false;
   // longest possible chain is floor((maxcount-1)/K)+1 heads
   const uint32_t mc = *a.maxcount;
-  if (mc == 0 || d >= (mc - 1) / a.K + 1) return 0;
+  if (mc == 0 || d >= (mc - 1) / a.K + 1) return false;
   const uint64_t slot = (uint64_t)w * a.G + g;
   const uint32_t b = a.hkey[slot];
-  if (b == KEY_NONE) return 0;
+  if (b == KEY_NONE) return false;
   const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
   const uint32_t s = bs[b] / a.K + 1;
   const uint32_t e = (bs[b + 1] - 1) / a.K;
   const uint32_t rel = g - s;
-  if ((rel % (4 * d)) != 0 || g + d > e) return 0;
-  const uint32_t left = (e - g) / d;
-  return left < 3 ? left : 3;
+  return (rel % (2 * d)) == 0 && g + d <= e;
 }
 template <class F>
 CTT_HD void merge_step_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint32_t d) {
-  const uint32_t np = merge_step_partners<F>(a, w, g, d);
-  if (np == 0) return;
+  if (!merge_step_active<F>(a, w, g, d)) return;
   const uint64_t slot = (uint64_t)w * a.G + g;
   XYZZ<F> x = a.heads[slot];
-  for (uint32_t j = 1; j <= np; j++) {
-    XYZZ<F> y = a.heads[slot + (uint64_t)j * d];
-    x = xyzz_add_inl<F>(x, y);
-  }
-  a.heads[slot] = x;
+  XYZZ<F> y = a.heads[slot + d];
+  a.heads[slot] = xyzz_add_inl<F>(x, y);
 }
 
 // the first head of each chain now holds the bucket sum

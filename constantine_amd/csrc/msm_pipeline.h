@@ -45,7 +45,7 @@ struct MsmOptions {
 //   accumulate  W*N mixed adds at 0.142 ns each (2.38 ms / 2^24 at full occupancy)
 //   reduce      c-1 passes of 12 us latency each, plus 2*2^(c-1)*W adds of work at 0.24 ns (fitted to 0.43 ms at c = 16,
 //               0.185 ms at c = 13)
-//   merge       45 us + one 28 us tree step per doubling of the longest head chain (fitted before the tree became radix 4).  The top window only has
+//   merge       45 us + one 28 us tree step per doubling of the longest head chain.  The top window only has
 //               bits - (W-1)*c significant bits: when that is small its few buckets each receive N/2^(top-1)
 //               entries and the chain is long -- the model steers away from such c (e.g. c = 14 at N = 2^18)
 //   sort        0.02 ns per (window, pair) + 60 us
@@ -349,7 +349,7 @@ struct MsmEngine {
     const uint32_t chain = mc ? (mc - 1) / p.K + 1 : 0;
     bk.template launch_merge_tail<FD>(ma, p.W, chain <= 1);
     if (chain > 1) {
-      for (uint32_t d = 1; d < chain; d <<= 2) bk.template launch_merge_step<FD>(ma, p.W, d);   // radix-4 tree
+      for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<FD>(ma, p.W, d);
       bk.template launch_merge_final<FD>(ma, p.W);
     }
     bk.stage_end(sl, ST_MERGE);
@@ -569,7 +569,7 @@ struct MsmEngine {
     bk.template launch_accum<FD>(aa, 1);
     MergeArgs<FD> ma{d_bstart, d_buckets, d_heads, d_tails, d_hkey, d_tkey, d_maxcount, 1, K, G};
     bk.template launch_merge_tail<FD>(ma, 1, false);
-    for (uint32_t d = 1; d < G; d <<= 2) bk.template launch_merge_step<FD>(ma, 1, d);
+    for (uint32_t d = 1; d < G; d <<= 1) bk.template launch_merge_step<FD>(ma, 1, d);
     bk.template launch_merge_final<FD>(ma, 1);
     XYZZ<FD> raw;
     bk.d2h_sync(&raw, d_buckets, sizeof(raw));
