@@ -403,15 +403,22 @@ struct HipBackend {
     HIP_CHECK(hipEventSynchronize(ev_word));
     return *h_word;
   }
+  // Stage timing is opt-in (ctt_hip_msm_set_option "timings"): twelve event records per MSM are host time a caller of a
+  // small MSM should not pay for a number it does not read.
+  bool timing = false;
   void stage_begin(int slot, int s) {
+    if (!timing) return;
     HIP_CHECK(hipEventRecord(ev_begin[slot][s], stream));
     ev_used[slot][s] = true;
   }
-  void stage_end(int slot, int s) { HIP_CHECK(hipEventRecord(ev_end[slot][s], cur())); }
+  void stage_end(int slot, int s) {
+    if (timing) HIP_CHECK(hipEventRecord(ev_end[slot][s], cur()));
+  }
   // stage times of the MSM that used `slot` (call after its finish())
   void collect_timings(int slot) {
     for (int i = 0; i < ST_COUNT; i++) {
-      if (!ev_used[slot][i]) continue;
+      if (!timing) stage_ms[i] = 0.f;
+      if (!timing || !ev_used[slot][i]) continue;
       HIP_CHECK(hipEventSynchronize(ev_end[slot][i]));
       HIP_CHECK(hipEventElapsedTime(&stage_ms[i], ev_begin[slot][i], ev_end[slot][i]));
     }

@@ -167,6 +167,10 @@ class DeviceMsm:
                                        self._dptr(d_src), n, 1) != 0:
             raise RuntimeError("ctt_hip_batch_affine failed")
 
+    def enable_timings(self, on=True):
+        """Record the per-stage HIP events that last_timings() reads (off by default: they are host time per MSM)."""
+        self.set_option("timings", 1 if on else 0)
+
     def last_timings(self):
         ms = np.zeros(6, dtype=np.float32)
         self.L.ctt_hip_msm_last_timings(self.ctx, _ptr(ms), 6)

@@ -145,7 +145,8 @@ void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
 /* key: "c" window bits, "K" sorted entries per accumulate lane, "S" scalars per sort-partition workgroup, "chunks" slices a
  * host-pointer call is uploaded in (the upload of slice i+1 runs underneath the accumulation of slice i),
  * "host_window_sums" where the Horner over a window's bit sums runs (0 automatic: on the device unless the caller keeps MSMs
- * in flight, 1 host, 2 device).  value 0 = automatic.  Returns 0, or -1 for an unknown key. */
+ * in flight, 1 host, 2 device), "timings" 1 = record the stage events ctt_hip_msm_last_timings reads.  value 0 = automatic /
+ * off.  Returns 0, or -1 for an unknown key. */
 int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
 /* r (HOST memory, `out_kind` layout) = sum coefs[i] * points[i]; d_coefs / d_points are DEVICE pointers
  * (BigInt canonical or Fr Montgomery 32-byte scalars; affine Montgomery points, C-API struct layout).
@@ -187,7 +188,8 @@ ctt_hip_msm_bases* ctt_hip_msm_bases_create(ctt_hip_msm_ctx* ctx, int curve, con
 void ctt_hip_msm_bases_destroy(ctt_hip_msm_ctx* ctx, ctt_hip_msm_bases* bases);
 int ctt_hip_msm_with_bases(ctt_hip_msm_ctx* ctx, const ctt_hip_msm_bases* bases, int coef_kind, int out_kind, void* r,
                            const void* coefs, size_t len, int coefs_on_device);
-/* HIP-event stage times (ms) of the last finished MSM: digits, sort, accumulate, merge, reduce, total. */
+/* HIP-event stage times (ms) of the last finished MSM: digits, sort, accumulate, merge, reduce, total.  Opt-in: set the
+ * option "timings" to 1 first (the events are host time per MSM; without it the call returns zeros). */
 int ctt_hip_msm_last_timings(ctt_hip_msm_ctx* ctx, float* ms, int cap);
 /* plan of the last call: c, W, K, G, S, resident lanes */
 int ctt_hip_msm_last_plan(ctt_hip_msm_ctx* ctx, int* out, int cap);
