@@ -215,27 +215,31 @@ CTT_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& q, bool neg) {
   if (empty) acc = XYZZ<F>::inf();
 }
 
-// acc += q, both XYZZ; returns by value so that neither operand has its address taken
+// acc += q, both XYZZ; returns by value so that neither operand has its address taken.  Bounds in units of p: in X < 9, Y < 4,
+// ZZ, ZZZ < 2; out the same.  Lazy operands as in xyzz_madd_flag.
 template <class F>
 CTT_HD XYZZ<F> xyzz_add_inl(const XYZZ<F>& a, const XYZZ<F>& q) {
   constexpr int M = F::MULB;
+  constexpr bool L1 = LazyOps<F>::ONE, L2 = LazyOps<F>::BOTH;
+  constexpr int XB = XYZZ_XB;
   if (q.is_inf()) return a;
   if (a.is_inf()) return q;
   F U1, U2, S1, S2;
-  fmul_pair<F>(a.x, q.zz, q.x, a.zz, U1, U2);
-  fmul_pair<F>(a.y, q.zzz, q.y, a.zzz, S1, S2);
-  F P = fsub<F, M>(U2, U1);                      // < 2M
-  F R = fsub<F, M>(S2, S1);                      // < 2M
-  if (fis_zero_modp<F, 2 * M>(P)) {
-    if (fis_zero_modp<F, 2 * M>(R)) return xyzz_dbl<F>(a);
+  fmul_pair<F>(a.x, q.zz, q.x, a.zz, U1, U2);                 // 9*2
+  fmul_pair<F>(a.y, q.zzz, q.y, a.zzz, S1, S2);               // 4*2
+  F P = fsub_lz<F, M, L2>(U2, U1);                            // < 2 + 3 = 5
+  F R = fsub_lz<F, M, L2>(S2, S1);                            // < 5
+  if (fis_zero_modp<F, 2 * M + 1>(P)) {
+    if (fis_zero_modp<F, 2 * M + 1>(R)) return xyzz_dbl<F>(a);
     return XYZZ<F>::inf();
   }
   F PP, RR, PPP, Q, Z2, Z3;
-  fsqr_pair<F>(P, R, PP, RR);
+  fsqr_pair<F>(P, R, PP, RR);                                 // 25, 25
   fmul_pair<F>(P, PP, U1, PP, PPP, Q);
   XYZZ<F> r;
-  r.x = fsub<F, 2 * M>(fsub<F, M>(RR, PPP), F::dbl(Q));               // < 4M
-  r.y = fmul_sub<F, M>(R, fsub<F, 4 * M>(Q, r.x), S1, PPP);          // R*(Q-X3) - S1*PPP, < 2M
+  r.x = fsub3<F, 7>(RR, PPP, Q);                              // RR - PPP - 2Q + 7p < 9
+  F T = fsub_lz<F, XB, L1>(Q, r.x);                           // < 2 + 10 = 12
+  r.y = fmul_sub_lz<F, M, L1>(R, T, S1, PPP);                 // R*T - S1*PPP: 5*12 + 3*2 = 66; < 2
   fmul_pair<F>(a.zz, q.zz, a.zzz, q.zzz, Z2, Z3);
   fmul_pair<F>(Z2, PP, Z3, PPP, r.zz, r.zzz);
   return r;
