@@ -5,6 +5,8 @@
  * usage: t_msm_c_abi <in.bin> <out.bin>
  *   in.bin : u64 n | n * big255 (32 B) | n * bls12_381_g1_aff (96 B)
  *   out.bin: bls12_381_g1_jac (parallel symbol, big coefs) | bls12_381_g1_prj (serial symbol, big coefs)
+ *            | bls12_381_g1_jac (parallel symbol again, the call sharded over two contexts on device 0:
+ *              ctt_hip_msm_set_devices) | n bytes of ctt_hip_subgroup_check flags
  * Built and driven by tests/test_gpu_parity.py::test_c_program_through_the_header. */
 #include <stdint.h>
 #include <stdio.h>
@@ -30,11 +32,24 @@ int main(int argc, char** argv) {
   ctt_bls12_381_g1_jac_multi_scalar_mul_big_coefs_vartime_parallel(tp, &rj, coefs, points, (size_t)n);
   ctt_bls12_381_g1_prj_multi_scalar_mul_big_coefs_vartime(&rp, coefs, points, (size_t)n);
 
+  /* the same call cut in two slices, one context each (what CTT_HIP_DEVICES=0,1 does on a two-GPU node) */
+  bls12_381_g1_jac rs;
+  const int devs[2] = {0, 0};
+  if (ctt_hip_msm_set_devices(devs, 2) != 0) return 8;
+  ctt_hip_msm_set_shard_min(100);
+  ctt_bls12_381_g1_jac_multi_scalar_mul_big_coefs_vartime_parallel(tp, &rs, coefs, points, (size_t)n);
+  if (ctt_hip_msm_set_devices(devs, 0) != 0) return 9;
+  uint8_t* ok = (uint8_t*)malloc(n);
+  if (ctt_hip_subgroup_check(NULL, CTT_HIP_BLS12_381_G1, ok, points, (size_t)n, 0) != 0) return 10;
+
   f = fopen(argv[2], "wb");
   if (!f) return 7;
   fwrite(&rj, sizeof rj, 1, f);
   fwrite(&rp, sizeof rp, 1, f);
+  fwrite(&rs, sizeof rs, 1, f);
+  fwrite(ok, 1, n, f);
   fclose(f);
+  free(ok);
   free(coefs);
   free(points);
   return 0;

@@ -490,6 +490,26 @@ def test_host_symbols_upload_in_slices():
         L.ctt_hip_msm_set_option(None, b"chunks", 0)
 
 
+def test_stage_timings_are_opt_in(torch_cuda):
+    """ctt_hip_msm_last_timings reads HIP events that are only recorded after set_option("timings", 1)."""
+    torch = torch_cuda
+    from constantine_amd import DeviceMsm
+    name = "pallas"
+    n = 30000
+    ds = _to_dev(torch, cref.synth_scalars(5, n, 255))
+    dp = _to_dev(torch, cref.gen_points(name, 6, n))
+    d = DeviceMsm(0)
+    try:
+        r0 = bytes(d.msm(name, ds, dp, n))
+        assert all(v == 0.0 for v in d.last_timings().values())
+        d.enable_timings()
+        assert bytes(d.msm(name, ds, dp, n)) == r0
+        t = d.last_timings()
+        assert t["accumulate"] > 0.0 and t["total"] >= t["accumulate"]
+    finally:
+        d.close()
+
+
 def test_api_misuse_returns_error_codes(dev, torch_cuda):
     """Recoverable misuse of the device-resident interface is an error code (RuntimeError here), not an abort: a third
     ticket on a curve, finishing a ticket twice, a blocking call while two tickets are outstanding, cached bases used
@@ -613,10 +633,12 @@ def test_c_program_through_the_header(tmp_path):
         f.write(pts.tobytes())
     subprocess.check_call([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
     out = open(tmp_path / "out.bin", "rb").read()
-    assert len(out) == 2 * 144
+    assert len(out) == 3 * 144 + n
     expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
     assert curve.jac_from_bytes(out[:144]) == expect
-    assert curve.prj_from_bytes(out[144:]) == expect
+    assert curve.prj_from_bytes(out[144:288]) == expect
+    assert curve.jac_from_bytes(out[288:432]) == expect          # sharded over two contexts
+    assert out[432:] == b"\x01" * n                                # every generated point is in the subgroup
 
 
 def test_concurrent_callers_are_serialised():
