@@ -26,7 +26,7 @@ def exported_symbols():
             syms.append(f"ctt_{stem}_{coord}_batch_affine")
     syms += ["ctt_hip_sum_reduce", "ctt_hip_batch_affine", "ctt_hip_msm_abi_version", "ctt_hip_msm_ctx_create", "ctt_hip_msm_ctx_destroy", "ctt_hip_msm_set_option",
              "ctt_hip_msm_device", "ctt_hip_msm_device_submit", "ctt_hip_msm_device_finish", "ctt_hip_msm_sync", "ctt_hip_msm_bases_create", "ctt_hip_msm_bases_destroy",
-             "ctt_hip_msm_with_bases", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
+             "ctt_hip_msm_with_bases", "ctt_hip_msm_with_bases_submit", "ctt_hip_msm_bases_create_table", "ctt_hip_msm_bases_window_bits", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
              "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream", "ctt_hip_msm_wait_stream",
              "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min", "ctt_hip_subgroup_check"]
     return syms
@@ -85,6 +85,12 @@ def lib():
     L.ctt_hip_msm_device_finish.argtypes = [vp, i32, i32, vp]
     L.ctt_hip_msm_bases_create.argtypes = [vp, i32, vp, sz, i32]
     L.ctt_hip_msm_bases_create.restype = vp
+    L.ctt_hip_msm_bases_create_table.argtypes = [vp, i32, vp, sz, i32, i32]
+    L.ctt_hip_msm_bases_create_table.restype = vp
+    L.ctt_hip_msm_bases_window_bits.argtypes = [vp]
+    L.ctt_hip_msm_bases_window_bits.restype = i32
+    L.ctt_hip_msm_with_bases_submit.argtypes = [vp, vp, i32, vp, sz]
+    L.ctt_hip_msm_with_bases_submit.restype = i32
     L.ctt_hip_msm_bases_destroy.argtypes = [vp, vp]
     L.ctt_hip_msm_bases_destroy.restype = None
     L.ctt_hip_msm_with_bases.argtypes = [vp, vp, i32, i32, vp, vp, sz, i32]

@@ -276,6 +276,12 @@ __global__ void __launch_bounds__(EC_BLOCK) k_subgroup_check(const Affine<typena
   subgroup_check_body<C>(pts, n, ok, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// one level of a window table: next = 2^c * prev (msm_bodies.h table_next_body; run once per table)
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_table_next(const Affine<F>* prev, Affine<F>* next, uint32_t n, int c) {
+  table_next_body<F>(prev, next, n, c, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // probe of the device field FD (msm_bodies.h dev_field_probe): inputs in the reference representation, output = raw FD limbs
 template <class F, class FD>
 __global__ void k_field_op_dev(int op, const F* a, const F* b, FD* r, uint32_t n) {
@@ -445,6 +451,12 @@ struct HipBackend {
     hipLaunchKernelGGL((k_convert_points<F, FD>), grid1(n, 256), dim3(256), 0, stream, in, out, n);
     HIP_CHECK(hipGetLastError());
   }
+  template <class F>
+  void launch_table_next(const Affine<F>* prev, Affine<F>* next, uint32_t n, int c) {
+    hipLaunchKernelGGL(k_table_next<F>, grid1(n, EC_BLOCK), dim3(EC_BLOCK), 0, stream, prev, next, n, c);
+    HIP_CHECK(hipGetLastError());
+  }
+  void sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
   void launch_digits_sort(const SortArgs& a);  // msm_engine.hip
   template <class F>
   void launch_accum(const AccumArgs<F>& a, uint32_t W) {
@@ -513,8 +525,9 @@ struct CurveOps {
                      void* d_stage_coefs, void* d_stage_points, int chunks, int* plan);
   // cached bases: device records for `n` points (d_points in the C-API layout, device memory); submit against them
   void* (*bases_prepare)(void* eng, const void* d_points, uint32_t n);
+  // (table_c > 0: d_prepared is a window table over table_n bases made by table_prepare)
   int (*submit_bases)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_prepared,
-                      uint32_t n, int* plan);
+                      uint32_t n, int table_c, uint32_t table_n, int* plan);
   void (*gen_points)(HipBackend* bk, uint64_t seed, uint64_t first, uint32_t n, void* d_out);
   void (*field_op)(HipBackend* bk, int op, const void* d_a, const void* d_b, void* d_r, uint32_t n);
   // host-only: r_aff = sum of n affine points (combining the per-GPU partial results of a sharded MSM,
@@ -527,6 +540,8 @@ struct CurveOps {
   size_t fe_bytes;  // one coordinate
   // ok[j] = [r]P_j is the neutral element (r = the curve order), n points and n flags in device memory
   void (*subgroup_check)(HipBackend* bk, const void* d_points, uint32_t n, void* d_ok);
+  // window table over n bases (MsmEngine::prepare_table): records of 2^(c*w) * P_j for every digit window; c = 0 chooses
+  void* (*table_prepare)(void* eng, const void* d_points, uint32_t n, int c, int* c_out);
 };
 
 template <class C>
@@ -568,17 +583,21 @@ struct CurveImpl {
   static void* bases_prepare(void* eng, const void* d_points, uint32_t n) {
     return ((Engine*)eng)->prepare_bases((const Affine<F>*)d_points, n);
   }
+  // table_c > 0: d_prepared is a window table over table_n bases (table_prepare)
   static int submit_bases(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_prepared,
-                          uint32_t n, int* plan) {
+                          uint32_t n, int table_c, uint32_t table_n, int* plan) {
     Engine& e = *(Engine*)eng;
     uint32_t lanes = e.opt.lanes;
     e.opt = *opt;
     e.opt.lanes = lanes;
-    int sl = e.submit((const uint32_t*)d_coefs, coef_is_fr != 0, nullptr, n, d_prepared);
+    int sl = e.submit((const uint32_t*)d_coefs, coef_is_fr != 0, nullptr, n, d_prepared, table_c, table_n);
     if (sl < 0) return sl;
     const MsmPlan& p = e.last_plan;
-    plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
+    plan[0] = p.c; plan[1] = p.Wd; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
     return sl;
+  }
+  static void* table_prepare(void* eng, const void* d_points, uint32_t n, int c, int* c_out) {
+    return ((Engine*)eng)->prepare_table((const Affine<F>*)d_points, n, c, c_out);
   }
   static int finish(void* eng, int slot, void* r_host, int out_kind) {
     Engine& e = *(Engine*)eng;
@@ -636,7 +655,7 @@ struct CurveImpl {
     HIP_CHECK(hipGetLastError());
   }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F), subgroup_check};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F), subgroup_check, table_prepare};
     return &o;
   }
 };

@@ -65,25 +65,34 @@ CTT_HD uint32_t booth_digit_packed(const uint32_t* k, int w, int c) {
   return val ? (((val - 1u) << 1) | neg) : DIGIT_NONE;
 }
 
-// Digits + sort by bucket.  Output contract (what the accumulation consumes): for every window w,
-// entries[w][0..bucket_start[w][B]) = (point index | sign << 31) of every non-zero digit, grouped by bucket in
-// increasing bucket order (any order inside a bucket), bucket_start[w][b] = first position of bucket b, and
-// maxcount[0] = size of the largest bucket over all windows.
+// Digits + sort by bucket.  Output contract (what the accumulation consumes): for every bucket set r (one per window;
+// a single one for all windows in the window-table form below), entries[r][0..bucket_start[r][B]) = (point index | sign << 31)
+// of every non-zero digit, grouped by bucket in increasing bucket order (any order inside a bucket), bucket_start[r][b] =
+// first position of bucket b, and maxcount[0] = size of the largest bucket over all sets.
+//
+// Window-table form (`merged`): the points are a table T[w][j] = 2^(c*w) * P_j (MsmEngine::prepare_table), so that the
+// digit of window w of scalar j is a multiple of the table entry w*id_stride + j and ALL windows share ONE bucket set:
+// W = 1, nent = Wd*n entries, the "point index" of an entry is the table index.
 struct SortArgs {
   const uint32_t* scalars;  // [n][8] canonical
   uint32_t n;
   int c;
-  uint32_t W, B;
-  uint32_t NG, gshift;      // bucket groups per window; group = bucket >> gshift
+  uint32_t W, B;            // bucket sets, buckets per set
+  uint32_t Wd;              // digit windows per scalar (== W unless merged)
+  uint32_t merged;          // 1: every digit window goes to bucket set 0
+  uint32_t nent;            // capacity of one set's entry list: n, or Wd*n when merged
+  uint32_t id_stride;       // merged: table entries per window (>= n: a prefix of the cached bases may be used)
+  uint32_t NG, gshift;      // bucket groups per set; group = bucket >> gshift
   uint32_t gshift_top;      // same for the top window W-1, whose digits only reach 2^(bits - (W-1)c) buckets
   uint32_t slice, nblk;     // partition pass: scalars per block, number of blocks
+  uint32_t chunk;           // partition pass: scalars a block stages in LDS at a time
   uint32_t jbits;           // bits of a point index: record = low bucket bits << (jbits+1) | sign << jbits | index
-  uint32_t* part;           // [W][n] packed records partitioned by group
+  uint32_t* part;           // [W][nent] packed records partitioned by group
   uint32_t* cntA;           // [nblk][W*NG] per-block group counts -> block offsets inside the group
   uint32_t* gtot;           // [W*NG] group sizes
-  uint32_t* gbase;          // [W][NG+1] group start inside the window
+  uint32_t* gbase;          // [W][NG+1] group start inside the set
   uint32_t* bstart;         // [W][B+1]
-  uint32_t* entries;        // [W][n]
+  uint32_t* entries;        // [W][nent]
   uint32_t* maxcount;       // [2]: largest bucket; scratch word
   uint32_t cap, big;        // k_group_sort: entries per LDS tile; buckets above `big` bypass the LDS image
 };
@@ -601,6 +610,23 @@ CTT_HD void subgroup_check_body(const Affine<typename C::F>* pts, uint32_t n, ui
     if ((Fr::Params::P[i >> 5] >> (i & 31)) & 1u) xyzz_madd<F>(r, P, false);
   }
   ok[j] = r.is_inf() ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window table for cached bases: next[j] = 2^c * prev[j] (affine in, affine out; one inversion per point -- the table is
+// built once per set of bases, MsmEngine::prepare_table).  The neutral (0,0) and points of order two map to (0,0).
+// ---------------------------------------------------------------------------------------------
+template <class F>
+CTT_HD void table_next_body(const Affine<F>* prev, Affine<F>* next, uint32_t n, int c, uint32_t j) {
+  if (j >= n) return;
+  const Affine<F> p = prev[j];
+  if (p.is_inf()) {
+    next[j] = Affine<F>::inf();
+    return;
+  }
+  XYZZ<F> r = xyzz_mdbl<F>(p.x, p.y);
+  for (int i = 1; i < c; i++) r = xyzz_dbl<F>(r);
+  next[j] = xyzz_to_affine<F>(r);
 }
 
 // ---------------------------------------------------------------------------------------------

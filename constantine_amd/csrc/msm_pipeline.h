@@ -26,6 +26,12 @@ struct MsmPlan {
   uint32_t cap, big;  // sort pass B: LDS tile entries; bucket size above which the LDS image is bypassed
   uint32_t K;      // sorted entries per accumulate lane
   uint32_t G;      // accumulate lanes per window
+  // window-table form (make_table_plan): Wd digit windows share ONE bucket set (W = 1) of nent = Wd*n entries
+  int Wd;              // digit windows per scalar (== W otherwise)
+  uint32_t merged;     // 1 = window-table form
+  uint32_t nent;       // entries per bucket set: n, or Wd*n
+  uint32_t id_stride;  // table rows per window (the cached bases' length; a call may use a prefix)
+  uint32_t chunk;      // sort pass A: scalars a partition block stages in LDS at a time
 };
 
 struct MsmOptions {
@@ -135,6 +141,106 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   if (K < 4) K = 4;
   p.K = K;
   p.G = (n + K - 1) / K;
+  p.Wd = p.W;
+  p.merged = 0;
+  p.nent = n;
+  p.id_stride = 0;
+  p.chunk = 4096;
+  return p;
+}
+
+// Window bits of a window table over `ntab` bases (MsmEngine::prepare_table), chosen when the table is built: the table
+// fixes c for every later call.  One bucket set serves all windows, so the reduction costs 2*2^(c-1) additions once
+// instead of once per window and c can grow until those balance the (bits/c + 1)*N accumulations -- with the limits of the
+// sort (packed 32-bit records: low bucket bits | sign | table index, at most 16384 bucket groups of at most 1024 buckets).
+static inline int table_index_bits(uint64_t rows) {
+  int jb = 1;
+  while (jb < 31 && (1ull << jb) < rows) jb++;
+  return jb;
+}
+static inline bool table_plan_fits(uint32_t ntab, int bits, int c) {
+  const int Wd = bits / c + 1;
+  const uint64_t rows = (uint64_t)Wd * ntab;
+  if (rows > 0x7fffffffull) return false;
+  const int jb = table_index_bits(rows);
+  int gshift = 31 - jb;            // low bucket bits a record has room for
+  if (gshift > 10) gshift = 10;    // at most 1024 buckets per group
+  if (gshift < 0) return false;
+  const uint64_t NG = (uint64_t)(1u << (c - 1)) >> gshift;
+  return NG <= 16384u;
+}
+static inline int choose_table_window_bits(uint32_t ntab, int bits) {
+  // Same constants as choose_window_bits, one bucket set.  What differs is the top window: its digits only reach 2^top
+  // buckets (top = bits - (Wd-1)*c), and in the shared bucket set those buckets receive N/2^top entries on top of their
+  // share -- long head chains for the merge tree, and one bucket group that a single sort workgroup has to swallow
+  // (measured, BLS12-381 G1 2^20 bases: c = 20, top = 15: sort 0.29 ms, 2.68 ms per MSM; c = 19, top = 8: sort 0.68 ms,
+  // 3.17 ms; c = 21, top = 3: sort 1.39 ms, 4.42 ms).
+  double best = 1e300;
+  int bc = 0;
+  for (int c = 4; c <= 22; c++) {
+    if (!table_plan_fits(ntab, bits, c)) continue;
+    const int Wd = bits / c + 1;
+    const double B = (double)(1u << (c - 1));
+    const double total = (double)Wd * ntab;
+    const double K = (double)plan_entries_per_lane((uint32_t)(total > 4e9 ? 4e9 : total), 1, 131072);
+    const double acc = total * 0.142e-3;
+    const double red = (c - 1) * 12.0 + 2.0 * B * 0.24e-3;
+    const int top = bits - (Wd - 1) * c;
+    const double top_buckets = top > 0 ? (double)(1u << top) : 1.0;
+    double maxcnt = (double)ntab / top_buckets + total / B;
+    double chain = maxcnt / K;
+    int steps = 0;
+    while (chain > 1.0) { chain *= 0.5; steps++; }
+    const double mer = 45.0 + 28.0 * steps;
+    int gshift = 31 - table_index_bits((uint64_t)Wd * ntab);
+    if (gshift > 10) gshift = 10;
+    const double group_buckets = (double)(1u << gshift);
+    const double heavy = (double)ntab * (group_buckets < top_buckets ? group_buckets / top_buckets : 1.0);  // extra records of the heaviest group
+    const double srt = total * 0.02e-3 + 60.0 + heavy * 0.8e-3;
+    const double cost = acc + red + mer + srt;
+    if (cost < best) { best = cost; bc = c; }
+  }
+  return bc;
+}
+
+// Plan of one MSM over the first n bases of a window table built with c window bits over ntab bases.
+static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab, const MsmOptions& o) {
+  MsmPlan p;
+  p.n = n;
+  p.c = c;
+  p.Wd = bits / c + 1;
+  p.W = 1;
+  p.B = 1u << (c - 1);
+  p.merged = 1;
+  p.nent = (uint32_t)((uint64_t)p.Wd * n);
+  p.id_stride = ntab;
+  uint32_t slice = o.S > 0 ? (uint32_t)o.S : 2048u;
+  while (o.S <= 0 && (uint64_t)slice * 512u < n) slice <<= 1;
+  while (o.S <= 0 && slice > 64u && (uint64_t)slice * 64u > n) slice >>= 1;
+  p.slice = slice;
+  p.S = (n + slice - 1) / slice;
+  p.jbits = (uint32_t)table_index_bits((uint64_t)p.Wd * ntab);
+  p.cap = 20480u;
+  p.big = 1024u;
+  // groups of ~16384 entries, at most 1024 buckets per group, and the packed record must fit 32 bits
+  uint32_t NG = 1;
+  while ((uint64_t)NG * 16384u < p.nent && NG < 4096u) NG <<= 1;
+  while (NG < p.B && p.B / NG > 1024u) NG <<= 1;
+  if (NG > p.B) NG = p.B;
+  p.gshift = 0;
+  while ((p.B >> p.gshift) > NG) p.gshift++;
+  while (p.gshift > 0 && p.jbits + 1 + p.gshift > 32) { p.gshift--; NG <<= 1; }
+  p.NG = NG;
+  p.gshift_top = p.gshift;  // all windows share the groups
+  // partition pass: the NG group cursors and the staged scalars share 144 KiB of LDS
+  uint32_t chunk = (147456u - NG * 4u) / 32u;
+  chunk &= ~511u;
+  p.chunk = chunk > 4096u ? 4096u : chunk;
+  uint32_t K = o.K > 0 ? (uint32_t)o.K : plan_entries_per_lane(p.nent, 1, o.lanes);
+  K = (K + 3u) & ~3u;
+  if (K < 4) K = 4;
+  p.K = K;
+  p.G = (p.nent + K - 1) / K;
   return p;
 }
 
@@ -243,6 +349,39 @@ struct MsmEngine {
     }
   }
 
+  // Window table over bases that are reused across MSMs (an SRS, a commitment key): T[w][j] = 2^(c*w) * P_j for the
+  // Wd = bits/c + 1 digit windows, as converted point records.  With it every Booth digit of every window is a signed
+  // multiple of a TABLE row, all windows share one bucket set, and the doublings of the window combine disappear: an MSM
+  // is (bits/c + 1)*N accumulations and ONE bucket reduction over 2^(c-1) buckets -- so c is larger than without the
+  // table (20 instead of 16 at N = 2^20: 13 instead of 16 accumulations per pair).  The price is memory, Wd times the
+  // point records (1.7 GB for 2^20 BLS12-381 G1 bases: this is what 288 GB of HBM is for), and c*(Wd-1) doublings plus
+  // Wd-1 inversions per base when the table is built.  The reference has no such table; its nearest relative is the ZAL
+  // base descriptor (constantine-halo2-zal/src/lib.rs:68-95), which upstream passes through unchanged.
+  // Returns the records (caller-owned, free with bk.free); c = 0 chooses the window bits.  *c_out = the bits used.
+  void* prepare_table(const Affine<F>* d_points_in, uint32_t n, int c, int* c_out) {
+    if (c <= 0 || !table_plan_fits(n, C::BITS, c)) c = choose_table_window_bits(n, C::BITS);
+    *c_out = c;
+    if (n == 0 || c == 0) return nullptr;
+    const int Wd = C::BITS / c + 1;
+    const size_t stride = kConvert ? (size_t)gather_stride<FD>() : sizeof(Affine<F>);
+    char* tab = (char*)bk.alloc((size_t)Wd * n * stride);
+    Affine<F>* lvl[2] = {(Affine<F>*)bk.alloc((size_t)n * sizeof(Affine<F>)), (Affine<F>*)bk.alloc((size_t)n * sizeof(Affine<F>))};
+    const Affine<F>* cur = d_points_in;
+    for (int w = 0; w < Wd; w++) {
+      if (w > 0) {
+        Affine<F>* nxt = lvl[w & 1];
+        bk.template launch_table_next<F>(cur, nxt, n, c);
+        cur = nxt;
+      }
+      if constexpr (kConvert) bk.template launch_convert<F, FD>(cur, tab + (size_t)w * n * stride, n);
+      else bk.d2d_async(tab + (size_t)w * n * stride, cur, (size_t)n * sizeof(Affine<F>));
+    }
+    bk.sync();
+    bk.free(lvl[0]);
+    bk.free(lvl[1]);
+    return tab;
+  }
+
   // ---- the stages of one MSM ---------------------------------------------------------------------------------------
   // Stage 1 (per MSM, or per chunk of a host-pointer MSM): scalars -> Booth digits -> entries sorted by bucket ->
   // bucket sums of these pairs in `d_buckets` (heads/tails of the runs that straddle lane ranges still to be merged).
@@ -259,8 +398,8 @@ struct MsmEngine {
   // the grow-only workspace of stage 1 sized for plan p up front (need() frees and reallocates -- a device-wide
   // synchronisation -- when a later, larger slice of a host-pointer MSM asks for more)
   void reserve_stage1(const MsmPlan& p, bool coef_is_fr) {
-    const size_t W = p.W, n = p.n;
-    if (coef_is_fr) need(scal, n * 32);
+    const size_t W = p.W, n = p.nent;
+    if (coef_is_fr) need(scal, (size_t)p.n * 32);
     need(part, W * n * 4);
     need(counts, (size_t)p.S * W * p.NG * 4);
     need(totals, W * p.NG * 4);
@@ -304,16 +443,17 @@ struct MsmEngine {
     SortArgs sa;
     sa.scalars = d_scalars;
     sa.n = n; sa.c = p.c; sa.W = W; sa.B = B;
+    sa.Wd = (uint32_t)p.Wd; sa.merged = p.merged; sa.nent = p.nent; sa.id_stride = p.id_stride; sa.chunk = p.chunk;
     sa.NG = p.NG; sa.gshift = p.gshift; sa.gshift_top = p.gshift_top; sa.slice = p.slice; sa.nblk = p.S;
     sa.jbits = p.jbits;
     sa.cap = p.cap; sa.big = p.big;
-    sa.part = (uint32_t*)need(part, (size_t)W * n * 4);
+    sa.part = (uint32_t*)need(part, (size_t)W * p.nent * 4);
     sa.cntA = (uint32_t*)need(counts, (size_t)p.S * W * p.NG * 4);
     sa.gtot = (uint32_t*)need(totals, (size_t)W * p.NG * 4);
     sa.gbase = (uint32_t*)need(gbase, (size_t)W * (p.NG + 1) * 4);
     Staged st;
     st.d_bstart = (uint32_t*)need(bstart, (size_t)W * (B + 1) * 4);
-    uint32_t* d_entries = (uint32_t*)need(entries, (size_t)W * n * 4);
+    uint32_t* d_entries = (uint32_t*)need(entries, (size_t)W * p.nent * 4);
     st.d_maxcount = (uint32_t*)need(maxcount, 256);
     bk.memset0(st.d_maxcount, 8);
     sa.bstart = st.d_bstart; sa.entries = d_entries; sa.maxcount = st.d_maxcount;
@@ -333,7 +473,7 @@ struct MsmEngine {
     st.d_tails = (XYZZ<FD>*)need(tails, (size_t)W * p.G * sizeof(XYZZ<FD>));
     st.d_hkey = (uint32_t*)need(hkey, (size_t)W * p.G * 4);
     st.d_tkey = (uint32_t*)need(tkey, (size_t)W * p.G * 4);
-    AccumArgs<FD> aa{d_entries, st.d_bstart, d_points, point_stride, d_buckets, st.d_heads, st.d_tails, st.d_hkey, st.d_tkey, n, B, p.K, p.G};
+    AccumArgs<FD> aa{d_entries, st.d_bstart, d_points, point_stride, d_buckets, st.d_heads, st.d_tails, st.d_hkey, st.d_tkey, p.nent, B, p.K, p.G};
     bk.template launch_accum<FD>(aa, W);
     bk.stage_end(sl, ST_ACCUM);
     return st;
@@ -411,11 +551,12 @@ struct MsmEngine {
 
   // One MSM on device-resident inputs.  d_prepared (optional): records made by prepare_bases for the same points; skips
   // the per-MSM conversion.  Returns the slot, or -1 when both slots are in flight.
+  // d_prepared with table_c > 0: a window table built by prepare_table over table_n bases with table_c window bits.
   int submit(const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in, uint32_t n,
-             const void* d_prepared = nullptr) {
+             const void* d_prepared = nullptr, int table_c = 0, uint32_t table_n = 0) {
     const int sl = claim_slot(n);
     if (sl < 0 || n == 0) return sl;
-    const MsmPlan p = make_plan(n, C::BITS, opt);
+    const MsmPlan p = table_c > 0 ? make_table_plan(n, C::BITS, table_c, table_n, opt) : make_plan(n, C::BITS, opt);
     slots[sl].plan = p;
     last_plan = p;
     bk.stage_begin(sl, ST_TOTAL);

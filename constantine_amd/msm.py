@@ -241,9 +241,13 @@ def batchAffine_vartime(curve, points, coord="jac"):
 
 
 class CachedBases:
-    """Base points resident in HBM in the device representation (ctt_hip_msm_bases_*)."""
+    """Base points resident in HBM in the device representation (ctt_hip_msm_bases_*).
 
-    def __init__(self, curve, points, ctx=None, on_device=False):
+    table=True also keeps their multiples 2^(c*w) * P for every digit window (ctt_hip_msm_bases_create_table): (bits/c + 1)
+    times the memory, and every later MSM over these bases needs bits/c + 1 accumulations per pair into one bucket set
+    with a larger c than a table-less MSM (window_bits = 0: chosen from the number of bases), and no window combine."""
+
+    def __init__(self, curve, points, ctx=None, on_device=False, table=False, window_bits=0):
         self.L = _lib.lib()
         self.curve = curve
         self.info = CURVES[curve]
@@ -259,11 +263,41 @@ class CachedBases:
                 raise ValueError(f"points must have shape (n, {self.info.aff_bytes})")
             self.n = points.shape[0]
             ptr = _ptr(points)
-        self.handle = self.L.ctt_hip_msm_bases_create(ctx, self.info.cid, ptr, self.n, 1 if on_device else 0)
+        if table:
+            self.handle = self.L.ctt_hip_msm_bases_create_table(ctx, self.info.cid, ptr, self.n, 1 if on_device else 0,
+                                                                int(window_bits))
+        else:
+            self.handle = self.L.ctt_hip_msm_bases_create(ctx, self.info.cid, ptr, self.n, 1 if on_device else 0)
         if not self.handle:
             raise RuntimeError("ctt_hip_msm_bases_create failed")
+        self.window_bits = self.L.ctt_hip_msm_bases_window_bits(self.handle)  # 0 = plain records
+
+    def submit(self, d_coefs, n, fr_coefs=False):
+        """Coefficients resident on the device (torch CUDA tensor or raw address): enqueue and return a ticket for
+        DeviceMsm.finish / CachedBases.finish (at most two outstanding per curve)."""
+        if n > self.n:
+            raise AssertionError("more coefficients than cached bases")
+        if hasattr(d_coefs, "data_ptr") and getattr(d_coefs, "is_cuda", False):
+            import torch
+            if self.L.ctt_hip_msm_wait_stream(self.ctx, ctypes.c_void_p(torch.cuda.current_stream(d_coefs.device).cuda_stream)) != 0:
+                raise RuntimeError("ctt_hip_msm_wait_stream failed")
+        t = self.L.ctt_hip_msm_with_bases_submit(self.ctx, self.handle, COEF_FR if fr_coefs else COEF_BIG,
+                                                 DeviceMsm._dptr(d_coefs), n)
+        if t < 0:
+            raise RuntimeError("ctt_hip_msm_with_bases_submit failed (wrong context, or two tickets already outstanding)")
+        return (self.curve, t)
+
+    def finish(self, ticket, coord="prj"):
+        curve, t = ticket
+        nco = 2 if coord == "aff" else 3
+        r = np.zeros(nco * self.info.coord_bytes, dtype=np.uint8)
+        if self.L.ctt_hip_msm_device_finish(self.ctx, t, _COORD[coord], _ptr(r)) != 0:
+            raise RuntimeError("ctt_hip_msm_device_finish failed (ticket not outstanding)")
+        return r
 
     def msm(self, coefs, coord="prj", fr_coefs=False):
+        if hasattr(coefs, "data_ptr") and getattr(coefs, "is_cuda", False):
+            return self.finish(self.submit(coefs, int(coefs.shape[0]), fr_coefs=fr_coefs), coord=coord)
         coefs = np.ascontiguousarray(coefs, dtype=np.uint8)
         if coefs.ndim != 2 or coefs.shape[1] != 32:
             raise ValueError("coefs must have shape (n, 32)")
@@ -303,8 +337,9 @@ class CttEngine:
     def get_coeffs_descriptor(self, coeffs):
         return np.ascontiguousarray(coeffs, dtype=np.uint8)
 
-    def get_base_descriptor(self, bases):
-        return CachedBases(self.CURVE, bases)
+    def get_base_descriptor(self, bases, table=True):
+        # with the window table (CachedBases): bits/c + 1 multiples of every base resident in HBM, one bucket set per MSM
+        return CachedBases(self.CURVE, bases, table=table)
 
     def msm_with_cached_scalars(self, coeffs_desc, bases):
         return self.msm(coeffs_desc, bases)

@@ -188,6 +188,19 @@ ctt_hip_msm_bases* ctt_hip_msm_bases_create(ctt_hip_msm_ctx* ctx, int curve, con
 void ctt_hip_msm_bases_destroy(ctt_hip_msm_ctx* ctx, ctt_hip_msm_bases* bases);
 int ctt_hip_msm_with_bases(ctt_hip_msm_ctx* ctx, const ctt_hip_msm_bases* bases, int coef_kind, int out_kind, void* r,
                            const void* coefs, size_t len, int coefs_on_device);
+/* split form (device-resident coefficients): a ticket for ctt_hip_msm_device_finish, or -1 */
+int ctt_hip_msm_with_bases_submit(ctt_hip_msm_ctx* ctx, const ctt_hip_msm_bases* bases, int coef_kind, const void* d_coefs,
+                                  size_t len);
+/* Cached bases WITH A WINDOW TABLE: besides the bases themselves their multiples 2^(c*w) * P, w = 0 .. bits/c, are computed
+ * once and stay resident ((bits/c + 1) x the memory: 1.7 GB for 2^20 BLS12-381 G1 bases at c = 20).  Every Booth digit
+ * of every window then selects a table row, all windows share one bucket set, and the window combine (the doublings of
+ * ec_multi_scalar_mul.nim:250-254) disappears: a later ctt_hip_msm_with_bases[_submit] call costs bits/c + 1 accumulations
+ * per pair with a larger c than the table-less MSM can afford (13 instead of 16 at 2^20 pairs) and ONE bucket reduction.
+ * The result is the same group element.  window_bits = 0 chooses c from len; ctt_hip_msm_bases_window_bits returns the c
+ * in use (0 = plain records: no c fits the sort's packed records for this len). */
+ctt_hip_msm_bases* ctt_hip_msm_bases_create_table(ctt_hip_msm_ctx* ctx, int curve, const void* points, size_t len,
+                                                  int points_on_device, int window_bits);
+int ctt_hip_msm_bases_window_bits(const ctt_hip_msm_bases* bases);
 /* HIP-event stage times (ms) of the last finished MSM: digits, sort, accumulate, merge, reduce, total.  Opt-in: set the
  * option "timings" to 1 first (the events are host time per MSM; without it the call returns zeros). */
 int ctt_hip_msm_last_timings(ctt_hip_msm_ctx* ctx, float* ms, int cap);

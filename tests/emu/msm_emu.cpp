@@ -45,6 +45,11 @@ struct EmuBackend {
   void launch_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
     for (uint32_t j = 0; j < n; j++) fr_from_mont_body<Fr>(in, out, n, j);
   }
+  template <class F>
+  void launch_table_next(const Affine<F>* prev, Affine<F>* next, uint32_t n, int c) {
+    for (uint32_t j = 0; j < n; j++) table_next_body<F>(prev, next, n, c, j);
+  }
+  void sync() {}
   template <class F, class FD>
   void launch_convert(const Affine<F>* in, void* out, uint32_t n) {
     for (uint32_t j = 0; j < n; j++) convert_point_body<F, FD>(in, out, n, j);
@@ -55,6 +60,31 @@ struct EmuBackend {
     const uint32_t n = a.n, B = a.B;
     std::vector<uint32_t> dg(n), cnt(B);
     *a.maxcount = 0;
+    if (a.merged) {
+      // window table: every digit window goes to the one bucket set, entry = table row w*id_stride + j
+      std::vector<uint32_t> all((size_t)a.Wd * n);
+      std::fill(cnt.begin(), cnt.end(), 0u);
+      for (uint32_t w = 0; w < a.Wd; w++)
+        for (uint32_t j = 0; j < n; j++) {
+          const uint32_t d = booth_digit_packed(a.scalars + 8ull * j, (int)w, a.c);
+          all[(size_t)w * n + j] = d;
+          if (d != DIGIT_NONE) cnt[d >> 1]++;
+        }
+      uint32_t run = 0;
+      for (uint32_t b = 0; b < B; b++) {
+        a.bstart[b] = run;
+        run += cnt[b];
+        *a.maxcount = std::max(*a.maxcount, cnt[b]);
+      }
+      a.bstart[B] = run;
+      std::vector<uint32_t> cur(a.bstart, a.bstart + B);
+      for (uint32_t w = 0; w < a.Wd; w++)
+        for (uint32_t j = 0; j < n; j++) {
+          const uint32_t d = all[(size_t)w * n + j];
+          if (d != DIGIT_NONE) a.entries[cur[d >> 1]++] = (w * a.id_stride + j) | ((d & 1u) << 31);
+        }
+      return;
+    }
     for (uint32_t w = 0; w < a.W; w++) {
       std::fill(cnt.begin(), cnt.end(), 0u);
       for (uint32_t j = 0; j < n; j++) {
@@ -110,6 +140,9 @@ struct EmuOps {
              int S, int* plan_out);
   // host-pointer form: the inputs are uploaded in `chunks` slices, one bucket set per slice (MsmEngine::submit_host)
   int (*msm_host)(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c, int chunks);
+  // cached bases with a window table over `ntab` points (MsmEngine::prepare_table), MSM over the first n; returns the c used
+  int (*msm_table)(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t ntab, size_t n, int c,
+                   int K);
   void (*gen)(uint64_t seed, uint64_t first, uint32_t n, void* out);
   void (*fop)(int op, const void* a, const void* b, void* r);
   int (*fop_dev)(int op, const void* a, const void* b, void* r);
@@ -162,6 +195,20 @@ struct EmuCurve {
     write_result<typename MsmEngine<C, EmuBackend>::HF>(r, res, out_kind);
     return (int)eng.last_chunks;
   }
+  static int msm_table(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t ntab, size_t n,
+                       int c, int K) {
+    EmuBackend bk;
+    MsmEngine<C, EmuBackend> eng(bk);
+    eng.opt.K = K;
+    eng.opt.lanes = 4096;
+    int cu = 0;
+    void* tab = eng.prepare_table((const Affine<F>*)points, (uint32_t)ntab, c, &cu);
+    int s0 = eng.submit((const uint32_t*)coefs, coef_is_fr != 0, nullptr, (uint32_t)n, tab, cu, (uint32_t)ntab);
+    auto res = eng.finish(s0);
+    if (tab) bk.free(tab);
+    write_result<typename MsmEngine<C, EmuBackend>::HF>(r, res, out_kind);
+    return cu;
+  }
   static void gen(uint64_t seed, uint64_t first, uint32_t n, void* out) {
     Affine<F> G = generator<C>();
     for (uint32_t j = 0; j < n; j++) gen_point_body<F>(G, seed, first, n, (Affine<F>*)out, j);
@@ -211,7 +258,7 @@ struct EmuCurve {
     for (uint32_t lane = 0; (uint64_t)lane * K < n; lane++) batch_affine_body<F>(a, lane);
   }
   static const EmuOps* ops() {
-    static const EmuOps o = {msm, msm_host, gen, fop, fop_dev, dev_info, sum_reduce, batch_affine};
+    static const EmuOps o = {msm, msm_host, msm_table, gen, fop, fop_dev, dev_info, sum_reduce, batch_affine};
     return &o;
   }
 };
@@ -261,6 +308,11 @@ int emu_msm_host(int curve, int coef_is_fr, int out_kind, void* r, const void* c
                  int chunks) {
   const EmuOps* o = ops_of(curve);
   return o ? o->msm_host(coef_is_fr, out_kind, r, coefs, points, n, c, chunks) : -1;
+}
+int emu_msm_table(int curve, int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t ntab, size_t n,
+                  int c, int K) {
+  const EmuOps* o = ops_of(curve);
+  return o ? o->msm_table(coef_is_fr, out_kind, r, coefs, points, ntab, n, c, K) : -1;
 }
 int emu_gen_points(int curve, uint64_t seed, uint64_t first, uint32_t n, void* out) {
   const EmuOps* o = ops_of(curve);

@@ -262,3 +262,37 @@ def test_head_chains_of_every_length_class():
         for c in (5, 9):
             out, plan = emu.msm(name, sc, pts, c=c, K=K)
             assert bytes(out) == bytes(expect), (n_equal, c)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_window_table_for_cached_bases(name):
+    """MsmEngine::prepare_table + the window-table plan: T[w][j] = 2^(c*w) * P_j, every digit window selects a table row,
+    all windows share one bucket set and there is no window combine.  Same element as the oracle for every c (including
+    divisors of the scalar width: the extra window), for a prefix of the cached bases, with neutral points among the
+    bases, equal points and scalars (doubling paths inside the shared buckets) and Fr Montgomery coefficients."""
+    curve = po.CURVES[name]
+    n = 120 if curve.F.degree == 1 else 24
+    pts = cref.gen_points(name, 801, n)
+    sc = cref.synth_scalars(802, n, curve.scalar_bits)
+    pts[5] = 0                          # a neutral base: every table row of it stays neutral
+    pts[9] = pts[8]
+    sc[9] = sc[8]                       # the same pair twice: the shared bucket doubles
+    expect, _ = cref.msm(name, sc, pts)
+    for c, K in ((0, 0), (3, 4), (5, 8), (15, 4)) if name == "bls12_381_g1" else ((0, 0), (5, 4)):
+        out, cu = emu.msm_table(name, sc, pts, c=c, K=K)
+        assert cu == c or c == 0
+        assert cu > 0
+        assert bytes(out) == bytes(expect), (name, c, cu)
+    # a prefix of the cached bases (table rows stay ntab apart)
+    m = n // 3
+    expect, _ = cref.msm(name, sc[:m], pts[:m])
+    out, _ = emu.msm_table(name, sc[:m], pts, c=6, K=4)
+    assert bytes(out) == bytes(expect)
+    if curve.F.degree == 1:
+        mont = cref.synth_scalars(803, n, 250)
+        expect, _ = cref.msm(name, cref.fr_from_mont(name, mont), pts)
+        out, _ = emu.msm_table(name, mont, pts, coef_is_fr=True, c=7)
+        assert bytes(out) == bytes(expect)
+        # all-zero scalars -> neutral
+        out, _ = emu.msm_table(name, np.zeros((n, 32), np.uint8), pts, c=4)
+        assert _aff(curve, out) is None

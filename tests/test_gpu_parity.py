@@ -198,10 +198,12 @@ def test_halo2_zal_engine_entry():
         can, mont = curve.scalars_to_array(ks), curve.fr_scalars_to_array(ks)
         expect = _aff(curve, cref.msm(name, can, pts, nthreads=NT)[0])
         assert curve.prj_from_bytes(bytes(eng.msm(mont, pts))) == expect
-        desc = eng.get_base_descriptor(pts)           # uploads + converts the bases once (lib.rs:68-71)
-        assert curve.prj_from_bytes(bytes(eng.msm_with_cached_base(mont, desc))) == expect
-        assert curve.prj_from_bytes(bytes(eng.msm_with_cached_base(mont, desc))) == expect
-        desc.close()
+        for table in (True, False):                   # with and without the window table (CachedBases)
+            desc = eng.get_base_descriptor(pts, table=table)   # uploads + converts the bases once (lib.rs:68-71)
+            assert (desc.window_bits > 0) == table
+            assert curve.prj_from_bytes(bytes(eng.msm_with_cached_base(mont, desc))) == expect
+            assert curve.prj_from_bytes(bytes(eng.msm_with_cached_base(mont, desc))) == expect
+            desc.close()
 
 
 @pytest.mark.parametrize("group,cname", [("g1", "bls12_381_g1"), ("g2", "bls12_381_g2")])
@@ -610,6 +612,72 @@ def test_cached_bases_prefix_and_reuse(name):
             assert _decode(curve, "jac", bases.msm(sc, coord="jac")) == expect
     finally:
         bases.close()
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_snarks_g1", "pallas", "vesta", "bls12_381_g2", "bn254_snarks_g2"])
+def test_window_table_cached_bases_vs_oracle(name):
+    """ctt_hip_msm_bases_create_table: the multiples 2^(c*w) * P of the bases are resident, every digit window selects a
+    table row, all windows share one bucket set (the merged form of the sort), no window combine.  Oracle parity for the
+    automatic c and explicit ones (small c: many windows and long bucket chains; c dividing the scalar width: the extra
+    window), prefixes of the bases, a neutral base, a repeated pair, Fr Montgomery coefficients."""
+    from constantine_amd import CachedBases
+    curve = po.CURVES[name]
+    n = 20000 if curve.F.degree == 1 else 1500
+    pts = cref.gen_points(name, 911, n)
+    pts[11] = 0
+    pts[13] = pts[12]
+    for wb in (0, 5, 12, 15) if curve.F.degree == 1 else (0, 9):
+        bases = CachedBases(name, pts, table=True, window_bits=wb)
+        try:
+            assert bases.window_bits == wb or (wb == 0 and bases.window_bits > 0)
+            for seed, m in ((1, n), (3, n // 3), (4, 1)):
+                sc = cref.synth_scalars(seed, m, curve.scalar_bits)
+                if m > 13:
+                    sc[13] = sc[12]
+                expect = _aff(curve, cref.msm(name, sc, pts[:m], nthreads=NT)[0])
+                assert _decode(curve, "jac", bases.msm(sc, coord="jac")) == expect, (name, wb, m)
+            if curve.F.degree == 1:
+                mont = cref.synth_scalars(5, n, 250)
+                expect = _aff(curve, cref.msm(name, cref.fr_from_mont(name, mont), pts, nthreads=NT)[0])
+                assert _decode(curve, "prj", bases.msm(mont, coord="prj", fr_coefs=True)) == expect
+            assert _decode(curve, "aff", bases.msm(np.zeros((n, 32), np.uint8), coord="aff")) is None
+        finally:
+            bases.close()
+
+
+@pytest.mark.parametrize("name,log2n", [("bls12_381_g1", 20), ("bn254_snarks_g1", 20)])
+def test_window_table_full_size_vs_oracle(name, log2n):
+    """The window-table form at a BASELINE size against the oracle (the automatic c: 20 at 2^20 bases, one set of 2^19
+    buckets, 13 table rows per base), device-resident coefficients, two MSMs in flight."""
+    import torch
+    from constantine_amd import CachedBases, DeviceMsm
+    from constantine_amd.msm import CURVES
+    from constantine_amd.synth import synth_scalars
+    curve = po.CURVES[name]
+    info = CURVES[name]
+    n = 1 << log2n
+    eng = DeviceMsm(0)
+    try:
+        d_points = torch.empty((n, info.aff_bytes), dtype=torch.uint8, device="cuda")
+        eng.gen_points(name, 0x7AB1E, n, d_points)
+        bases = CachedBases(name, d_points, ctx=eng.ctx, on_device=True, table=True)
+        try:
+            assert bases.window_bits >= 17
+            sc_a = synth_scalars(21, n, info.scalar_bits)
+            sc_b = synth_scalars(22, n, info.scalar_bits)
+            d_a, d_b = torch.from_numpy(sc_a).cuda(), torch.from_numpy(sc_b).cuda()
+            ta = bases.submit(d_a, n)
+            tb = bases.submit(d_b, n)
+            ra, rb = bases.finish(ta, coord="aff"), bases.finish(tb, coord="aff")
+            pts = d_points.cpu().numpy()
+            assert _decode(curve, "aff", ra) == _aff(curve, cref.msm(name, sc_a, pts, nthreads=NT)[0])
+            assert _decode(curve, "aff", rb) == _aff(curve, cref.msm(name, sc_b, pts, nthreads=NT)[0])
+            # and the table-less engine on the same inputs
+            assert bytes(eng.msm(name, d_a, d_points, n, coord="aff")) == bytes(ra)
+        finally:
+            bases.close()
+    finally:
+        eng.close()
 
 
 def test_c_program_through_the_header(tmp_path):

@@ -60,5 +60,15 @@ for k in 16 17 18 19 22 24; do
 done
 timeout 300 python tools/bench_batch_ops.py > "$OUT/batch_ops_$TAG.txt" 2>> "$OUT/bench.err"
 timeout 300 python tools/bench_hostptr.py > "$OUT/hostptr_$TAG.txt" 2>> "$OUT/bench.err"
+# cached bases with a window table next to the plain records (same box, same inputs): ms per pipelined step + stage times
+{
+  timeout 300 python tools/bench_table.py bls12_381_g1 20 0 19 21
+  timeout 300 python tools/bench_table.py bls12_381_g1 18 0
+  timeout 300 python tools/bench_table.py bls12_381_g1 16 0
+  timeout 300 python tools/bench_table.py bls12_381_g1 12 0
+  timeout 300 python tools/bench_table.py bn254_snarks_g1 22 0
+  timeout 300 python tools/bench_table.py pallas 20 0
+  timeout 300 python tools/bench_table.py bls12_381_g2 18 0
+} 2>> "$OUT/bench.err" | grep '^{' > "$OUT/table_$TAG.jsonl"
 find "$OUT/prof" -name "*.db" -delete 2>/dev/null   # the rocpd databases are large; the summaries are what is kept
 tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench_$TAG.json"
