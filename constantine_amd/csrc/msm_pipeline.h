@@ -31,7 +31,6 @@ struct MsmPlan {
   uint32_t merged;     // 1 = window-table form
   uint32_t nent;       // entries per bucket set: n, or Wd*n
   uint32_t id_stride;  // table rows per window (the cached bases' length; a call may use a prefix)
-  uint32_t chunk;      // sort pass A: scalars a partition block stages in LDS at a time
 };
 
 struct MsmOptions {
@@ -145,7 +144,6 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   p.merged = 0;
   p.nent = n;
   p.id_stride = 0;
-  p.chunk = 4096;
   return p;
 }
 
@@ -232,10 +230,6 @@ static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab
   while (p.gshift > 0 && p.jbits + 1 + p.gshift > 32) { p.gshift--; NG <<= 1; }
   p.NG = NG;
   p.gshift_top = p.gshift;  // all windows share the groups
-  // partition pass: the NG group cursors and the staged scalars share 144 KiB of LDS
-  uint32_t chunk = (147456u - NG * 4u) / 32u;
-  chunk &= ~511u;
-  p.chunk = chunk > 4096u ? 4096u : chunk;
   uint32_t K = o.K > 0 ? (uint32_t)o.K : plan_entries_per_lane(p.nent, 1, o.lanes);
   K = (K + 3u) & ~3u;
   if (K < 4) K = 4;
@@ -443,7 +437,7 @@ struct MsmEngine {
     SortArgs sa;
     sa.scalars = d_scalars;
     sa.n = n; sa.c = p.c; sa.W = W; sa.B = B;
-    sa.Wd = (uint32_t)p.Wd; sa.merged = p.merged; sa.nent = p.nent; sa.id_stride = p.id_stride; sa.chunk = p.chunk;
+    sa.Wd = (uint32_t)p.Wd; sa.merged = p.merged; sa.nent = p.nent; sa.id_stride = p.id_stride;
     sa.NG = p.NG; sa.gshift = p.gshift; sa.gshift_top = p.gshift_top; sa.slice = p.slice; sa.nblk = p.S;
     sa.jbits = p.jbits;
     sa.cap = p.cap; sa.big = p.big;

@@ -64,12 +64,18 @@ struct EmuBackend {
       // window table: every digit window goes to the one bucket set, entry = table row w*id_stride + j
       std::vector<uint32_t> all((size_t)a.Wd * n);
       std::fill(cnt.begin(), cnt.end(), 0u);
-      for (uint32_t w = 0; w < a.Wd; w++)
-        for (uint32_t j = 0; j < n; j++) {
-          const uint32_t d = booth_digit_packed(a.scalars + 8ull * j, (int)w, a.c);
+      // digits through the register walker the GPU's partition kernels use (for_each_digit), checked against the plain form
+      std::fill(all.begin(), all.end(), DIGIT_NONE);
+      for (uint32_t j = 0; j < n; j++) {
+        uint32_t k[1][8];
+        for (int q = 0; q < 8; q++) k[0][q] = a.scalars[8ull * j + q];
+        for_each_digit<1>(k, 0, a.Wd, a.c, [&](uint32_t w, const uint32_t (&dd)[1]) {
+          const uint32_t d = dd[0];
+          if (d != booth_digit_packed(a.scalars + 8ull * j, (int)w, a.c)) abort();
           all[(size_t)w * n + j] = d;
           if (d != DIGIT_NONE) cnt[d >> 1]++;
-        }
+        });
+      }
       uint32_t run = 0;
       for (uint32_t b = 0; b < B; b++) {
         a.bstart[b] = run;
@@ -88,7 +94,11 @@ struct EmuBackend {
     for (uint32_t w = 0; w < a.W; w++) {
       std::fill(cnt.begin(), cnt.end(), 0u);
       for (uint32_t j = 0; j < n; j++) {
-        dg[j] = booth_digit_packed(a.scalars + 8ull * j, (int)w, a.c);
+        dg[j] = DIGIT_NONE;
+        uint32_t k[1][8];
+        for (int q = 0; q < 8; q++) k[0][q] = a.scalars[8ull * j + q];
+        for_each_digit<1>(k, w, 1, a.c, [&](uint32_t, const uint32_t (&dd)[1]) { dg[j] = dd[0]; });   // the GPU kernels' digit walker
+        if (dg[j] != booth_digit_packed(a.scalars + 8ull * j, (int)w, a.c)) abort();
         if (dg[j] != DIGIT_NONE) cnt[dg[j] >> 1]++;
       }
       uint32_t* bs = a.bstart + (size_t)w * (B + 1);

@@ -1,12 +1,13 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out/r02g
-for K in "" 16 24 32; do
-  TABLE_K=$K timeout 600 python tools/bench_table.py bls12_381_g1 16 0 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r02g/table_bls_2pow16_K.jsonl
+export TMPDIR=/tmp
+for v in "" _ns4 _ns6; do
+for cfg in "bn254_snarks_g1 22" "bls12_381_g1 20"; do
+set -- $cfg
+rm -rf /tmp/prof_s && mkdir -p /tmp/prof_s
+( cd /tmp && CTT_MSM_HIP_LIB=/root/repo/constantine_amd/libctt_msm_hip$v.so rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o s -- python /root/repo/bench.py --curve $1 --log2n $2 --steps 6 --warmup 2 --no-cpu-baseline --no-latency > /tmp/prof_s/out.json 2> /tmp/prof_s/err.log )
+DB=$(find /tmp/prof_s -name "*.db" | head -1)
+echo "variant '$v' $1 $2"
+python tools/kernel_timeline.py "$DB" 2>&1 | grep -E "part_scatter"
 done
-for K in "" 16 32; do
-  TABLE_K=$K timeout 600 python tools/bench_table.py bls12_381_g1 12 0 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r02g/table_bls_2pow12_K.jsonl
-done
-for K in "" 48 64; do
-  TABLE_K=$K timeout 600 python tools/bench_table.py bls12_381_g1 18 0 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r02g/table_bls_2pow18_K.jsonl
 done
