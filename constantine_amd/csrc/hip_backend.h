@@ -30,9 +30,41 @@ __global__ void k_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
 static constexpr int ACCUM_BLOCK = 64;
 static constexpr int EC_BLOCK = 64;
 
+// Input points -> records (msm_bodies.h convert_point_body defines the record).  A lane converts its point into a record
+// held in LDS and the workgroup then streams the records out with consecutive 16-byte stores: written straight from the
+// lanes, every store instruction of a wave touched 64 different lines, 16 bytes each (the record stride is a whole line),
+// and the L2 had to merge 8 such partial writes per line.  The 16-byte chunks of a record are XOR-swizzled with the record
+// number so that both the lane-private writes and the linear read-out spread over all LDS banks.
+static constexpr int CONVERT_BLOCK = 128;
 template <class F, class FD>
-__global__ void k_convert_points(const Affine<F>* in, void* out, uint32_t n) {
-  convert_point_body<F, FD>(in, out, n, blockIdx.x * blockDim.x + threadIdx.x);
+__global__ void __launch_bounds__(CONVERT_BLOCK) k_convert_points(const Affine<F>* in, void* out, uint32_t n) {
+  constexpr uint32_t STRIDE = gather_stride<FD>(), CH = STRIDE / 16u;   // chunks per record (8, 16, ...: a power of two)
+  extern __shared__ uint4 cv_lds[];
+  const uint32_t t = threadIdx.x;
+  const uint32_t j0 = blockIdx.x * CONVERT_BLOCK, j = j0 + t;
+  union Rec {
+    uint4 q[CH];
+    struct { Affine<FD> a; } v;
+    uint32_t w[STRIDE / 4u];
+  };
+  if (j < n) {
+    Rec r;
+#pragma unroll
+    for (uint32_t i = 0; i < CH; i++) r.q[i] = make_uint4(0u, 0u, 0u, 0u);
+    const Affine<F> p = in[j];
+    r.v.a.x = FD::from_sat(p.x);
+    r.v.a.y = FD::from_sat(p.y);
+    r.w[gather_flag_offset<FD>() / 4u] = p.is_inf() ? 1u : 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < CH; i++) cv_lds[t * CH + (i ^ (t & (CH - 1u)))] = r.q[i];
+  }
+  __syncthreads();
+  const uint32_t cnt = (n - j0 < (uint32_t)CONVERT_BLOCK ? n - j0 : (uint32_t)CONVERT_BLOCK) * CH;
+  uint4* dst = reinterpret_cast<uint4*>((char*)out + (uint64_t)j0 * STRIDE);
+  for (uint32_t i = t; i < cnt; i += CONVERT_BLOCK) {
+    const uint32_t rec = i / CH, ch = i & (CH - 1u);
+    dst[i] = cv_lds[rec * CH + (ch ^ (rec & (CH - 1u)))];
+  }
 }
 
 #ifndef CTT_ACCUM_WAVES
@@ -448,7 +480,8 @@ struct HipBackend {
   }
   template <class F, class FD>
   void launch_convert(const Affine<F>* in, void* out, uint32_t n) {
-    hipLaunchKernelGGL((k_convert_points<F, FD>), grid1(n, 256), dim3(256), 0, stream, in, out, n);
+    hipLaunchKernelGGL((k_convert_points<F, FD>), grid1(n, CONVERT_BLOCK), dim3(CONVERT_BLOCK),
+                       (size_t)CONVERT_BLOCK * gather_stride<FD>(), stream, in, out, n);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>

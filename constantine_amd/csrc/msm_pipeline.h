@@ -459,10 +459,12 @@ struct MsmEngine {
     // conversion and sort to run underneath; the accumulation must not start before it is done: k_accum takes every
     // wave slot of the chip for its whole duration, and a tail kernel enqueued behind it would wait it out (measured on
     // a slower box: reduce span 2.4 ms, the pipeline slower than the serial order).  Worst case this is the serial order.
+    // (the bucket sets are cleared before that wait: the previous MSM read them in its first reduction pass, which is ahead
+    // of this point on the main stream, and its tail does not touch them)
+    bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
     bk.tail_wait();
     bk.stage_begin(sl, ST_ACCUM);
     st.d_buckets = d_buckets;
-    bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
     st.d_heads = (XYZZ<FD>*)need(heads, (size_t)W * p.G * sizeof(XYZZ<FD>));
     st.d_tails = (XYZZ<FD>*)need(tails, (size_t)W * p.G * sizeof(XYZZ<FD>));
     st.d_hkey = (uint32_t*)need(hkey, (size_t)W * p.G * 4);
