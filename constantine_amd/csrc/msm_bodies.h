@@ -105,7 +105,9 @@ CTT_HD void for_each_digit(const uint32_t (&k)[NS][8], uint32_t w0, uint32_t nw,
 //
 // Window-table form (`merged`): the points are a table T[w][j] = 2^(c*w) * P_j (MsmEngine::prepare_table), so that the
 // digit of window w of scalar j is a multiple of the table entry w*id_stride + j and ALL windows share ONE bucket set:
-// W = 1, nent = Wd*n entries, the "point index" of an entry is the table index.
+// W = 1, nent = Wd*n entries, the "point index" of an entry is the table row.  The partition pass then has one set of NG
+// group regions that every digit window of a block fills (the runs of a block are Wd times longer than without a table),
+// and its records are 64-bit: low bucket bits << 32 | sign << 31 | table row.
 struct SortArgs {
   const uint32_t* scalars;  // [n][8] canonical
   uint32_t n;
@@ -116,10 +118,10 @@ struct SortArgs {
   uint32_t nent;            // capacity of one set's entry list: n, or Wd*n when merged
   uint32_t id_stride;       // merged: table entries per window (>= n: a prefix of the cached bases may be used)
   uint32_t NG, gshift;      // bucket groups per set; group = bucket >> gshift
-  uint32_t gshift_top;      // same for the top window W-1, whose digits only reach 2^(bits - (W-1)c) buckets
+  uint32_t gshift_top;      // same for the top window W-1, whose digits only reach 2^(bits - (W-1)c) buckets (== gshift when merged)
   uint32_t slice, nblk;     // partition pass: scalars per block, number of blocks
-  uint32_t jbits;           // bits of a point index: record = low bucket bits << (jbits+1) | sign << jbits | index
-  uint32_t* part;           // [W][nent] packed records partitioned by group
+  uint32_t jbits;           // bits of a point index: 32-bit record = low bucket bits << (jbits+1) | sign << jbits | index
+  uint32_t* part;           // [W][nent] packed records partitioned by group (merged: 64-bit records, [nent])
   uint32_t* cntA;           // [nblk][W*NG] per-block group counts -> block offsets inside the group
   uint32_t* gtot;           // [W*NG] group sizes
   uint32_t* gbase;          // [W][NG+1] group start inside the set

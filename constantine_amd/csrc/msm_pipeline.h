@@ -149,8 +149,8 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
 
 // Window bits of a window table over `ntab` bases (MsmEngine::prepare_table), chosen when the table is built: the table
 // fixes c for every later call.  One bucket set serves all windows, so the reduction costs 2*2^(c-1) additions once
-// instead of once per window and c can grow until those balance the (bits/c + 1)*N accumulations -- with the limits of the
-// sort (packed 32-bit records: low bucket bits | sign | table index, at most 16384 bucket groups of at most 1024 buckets).
+// instead of once per window and c can grow until those balance the (bits/c + 1)*N accumulations (an entry is a table row |
+// sign << 31: at most 2^31 - 1 rows).
 static inline int table_index_bits(uint64_t rows) {
   int jb = 1;
   while (jb < 31 && (1ull << jb) < rows) jb++;
@@ -158,14 +158,8 @@ static inline int table_index_bits(uint64_t rows) {
 }
 static inline bool table_plan_fits(uint32_t ntab, int bits, int c) {
   const int Wd = bits / c + 1;
-  const uint64_t rows = (uint64_t)Wd * ntab;
-  if (rows > 0x7fffffffull) return false;
-  const int jb = table_index_bits(rows);
-  int gshift = 31 - jb;            // low bucket bits a record has room for
-  if (gshift > 10) gshift = 10;    // at most 1024 buckets per group
-  if (gshift < 0) return false;
-  const uint64_t NG = (uint64_t)(1u << (c - 1)) >> gshift;
-  return NG <= 16384u;
+  const uint64_t rows = (uint64_t)Wd * ntab;   // an entry is a table row | sign << 31
+  return rows <= 0x7fffffffull && Wd <= 128;
 }
 static inline int choose_table_window_bits(uint32_t ntab, int bits) {
   // Same constants as choose_window_bits, one bucket set.  What differs is the top window: its digits only reach 2^top
@@ -190,9 +184,11 @@ static inline int choose_table_window_bits(uint32_t ntab, int bits) {
     int steps = 0;
     while (chain > 1.0) { chain *= 0.5; steps++; }
     const double mer = 45.0 + 28.0 * steps;
-    int gshift = 31 - table_index_bits((uint64_t)Wd * ntab);
-    if (gshift > 10) gshift = 10;
-    const double group_buckets = (double)(1u << gshift);
+    // the heaviest bucket group: groups of ~12288 records (make_table_plan), the top window's records on top
+    double groups = 1.0;
+    while (groups * 12288.0 < total && groups < 4096.0) groups *= 2.0;
+    while (B / groups > 1024.0) groups *= 2.0;
+    const double group_buckets = B / groups;
     const double heavy = (double)ntab * (group_buckets < top_buckets ? group_buckets / top_buckets : 1.0);  // extra records of the heaviest group
     const double srt = total * 0.02e-3 + 60.0 + heavy * 0.8e-3;
     const double cost = acc + red + mer + srt;
@@ -217,17 +213,17 @@ static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab
   while (o.S <= 0 && slice > 64u && (uint64_t)slice * 64u > n) slice >>= 1;
   p.slice = slice;
   p.S = (n + slice - 1) / slice;
-  p.jbits = (uint32_t)table_index_bits((uint64_t)p.Wd * ntab);
+  p.jbits = 0;   // (the 64-bit partition records of this form hold the whole table row)
   p.cap = 20480u;
   p.big = 1024u;
-  // groups of ~16384 entries, at most 1024 buckets per group, and the packed record must fit 32 bits
+  // bucket groups of ~12288 records over all windows (the groups of the top window's buckets receive its records on top, and
+  // a group of up to 20480 is sorted in one sweep), at most 1024 buckets per group, and the packed record must fit 32 bits
   uint32_t NG = 1;
-  while ((uint64_t)NG * 16384u < p.nent && NG < 4096u) NG <<= 1;
+  while ((uint64_t)NG * 12288u < p.nent && NG < 4096u) NG <<= 1;
   while (NG < p.B && p.B / NG > 1024u) NG <<= 1;
   if (NG > p.B) NG = p.B;
   p.gshift = 0;
   while ((p.B >> p.gshift) > NG) p.gshift++;
-  while (p.gshift > 0 && p.jbits + 1 + p.gshift > 32) { p.gshift--; NG <<= 1; }
   p.NG = NG;
   p.gshift_top = p.gshift;  // all windows share the groups
   uint32_t K = o.K > 0 ? (uint32_t)o.K : plan_entries_per_lane(p.nent, 1, o.lanes);
@@ -394,7 +390,7 @@ struct MsmEngine {
   void reserve_stage1(const MsmPlan& p, bool coef_is_fr) {
     const size_t W = p.W, n = p.nent;
     if (coef_is_fr) need(scal, (size_t)p.n * 32);
-    need(part, W * n * 4);
+    need(part, W * n * (p.merged ? 8 : 4));
     need(counts, (size_t)p.S * W * p.NG * 4);
     need(totals, W * p.NG * 4);
     need(gbase, W * (p.NG + 1) * 4);
@@ -441,7 +437,7 @@ struct MsmEngine {
     sa.NG = p.NG; sa.gshift = p.gshift; sa.gshift_top = p.gshift_top; sa.slice = p.slice; sa.nblk = p.S;
     sa.jbits = p.jbits;
     sa.cap = p.cap; sa.big = p.big;
-    sa.part = (uint32_t*)need(part, (size_t)W * p.nent * 4);
+    sa.part = (uint32_t*)need(part, (size_t)W * p.nent * (p.merged ? 8 : 4));
     sa.cntA = (uint32_t*)need(counts, (size_t)p.S * W * p.NG * 4);
     sa.gtot = (uint32_t*)need(totals, (size_t)W * p.NG * 4);
     sa.gbase = (uint32_t*)need(gbase, (size_t)W * (p.NG + 1) * 4);
