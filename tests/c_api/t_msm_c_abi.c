@@ -6,7 +6,8 @@
  *   in.bin : u64 n | n * big255 (32 B) | n * bls12_381_g1_aff (96 B)
  *   out.bin: bls12_381_g1_jac (parallel symbol, big coefs) | bls12_381_g1_prj (serial symbol, big coefs)
  *            | bls12_381_g1_jac (parallel symbol again, the call sharded over two contexts on device 0:
- *              ctt_hip_msm_set_devices) | n bytes of ctt_hip_subgroup_check flags
+ *              ctt_hip_msm_set_devices) | bls12_381_g1_jac (cached bases with a window table:
+ *              ctt_hip_msm_bases_create_table + ctt_hip_msm_with_bases) | n bytes of ctt_hip_subgroup_check flags
  * Built and driven by tests/test_gpu_parity.py::test_c_program_through_the_header. */
 #include <stdint.h>
 #include <stdio.h>
@@ -42,11 +43,19 @@ int main(int argc, char** argv) {
   uint8_t* ok = (uint8_t*)malloc(n);
   if (ctt_hip_subgroup_check(NULL, CTT_HIP_BLS12_381_G1, ok, points, (size_t)n, 0) != 0) return 10;
 
+  /* the bases cached once with a window table (the ZAL base descriptor), then an MSM over them */
+  bls12_381_g1_jac rt;
+  ctt_hip_msm_bases* bases = ctt_hip_msm_bases_create_table(NULL, CTT_HIP_BLS12_381_G1, points, (size_t)n, 0, 0);
+  if (!bases || ctt_hip_msm_bases_window_bits(bases) <= 0) return 11;
+  if (ctt_hip_msm_with_bases(NULL, bases, CTT_HIP_COEF_BIG, CTT_HIP_OUT_JAC, &rt, coefs, (size_t)n, 0) != 0) return 12;
+  ctt_hip_msm_bases_destroy(NULL, bases);
+
   f = fopen(argv[2], "wb");
   if (!f) return 7;
   fwrite(&rj, sizeof rj, 1, f);
   fwrite(&rp, sizeof rp, 1, f);
   fwrite(&rs, sizeof rs, 1, f);
+  fwrite(&rt, sizeof rt, 1, f);
   fwrite(ok, 1, n, f);
   fclose(f);
   free(ok);

@@ -701,12 +701,13 @@ def test_c_program_through_the_header(tmp_path):
         f.write(pts.tobytes())
     subprocess.check_call([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
     out = open(tmp_path / "out.bin", "rb").read()
-    assert len(out) == 3 * 144 + n
+    assert len(out) == 4 * 144 + n
     expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
     assert curve.jac_from_bytes(out[:144]) == expect
     assert curve.prj_from_bytes(out[144:288]) == expect
     assert curve.jac_from_bytes(out[288:432]) == expect          # sharded over two contexts
-    assert out[432:] == b"\x01" * n                                # every generated point is in the subgroup
+    assert curve.jac_from_bytes(out[432:576]) == expect          # cached bases with a window table
+    assert out[576:] == b"\x01" * n                                # every generated point is in the subgroup
 
 
 def test_concurrent_callers_are_serialised():
