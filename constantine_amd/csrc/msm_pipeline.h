@@ -56,11 +56,29 @@ struct MsmOptions {
 //   sort        0.02 ns per (window, pair) + 60 us
 // Round-2 check against measurements (BLS12-381 G1, ms per pipelined step): 2^16 c = 13 0.709 / c = 16 0.756; 2^18 c = 16
 // 1.22 / c = 13 1.59; the round-1 constants still chose c = 13 at 2^17, where c = 16 is the faster plan.
+// Scalars per partition block (sort pass A).  Large n: 512 blocks, two per CU, ALL of the same size -- a power-of-two slice
+// made 257 blocks of 16384 scalars out of n = 2^22 + 77777, and the one CU that got two of them doubled the time of both
+// partition kernels (measured: sort 1.00 ms instead of 0.65 ms).  Small n: at least ~64 blocks.
+static inline uint32_t plan_partition_slice(uint32_t n, uint32_t min_slice) {
+  uint32_t slice = (uint32_t)(((uint64_t)n + 511u) / 512u);
+  slice = (slice + 255u) & ~255u;
+  if (slice < min_slice) slice = min_slice;
+  while (slice > 64u && (uint64_t)slice * 64u > n) slice >>= 1;
+  return slice;
+}
+
 static inline uint32_t plan_entries_per_lane(uint32_t n, int W, uint32_t lanes) {
   uint64_t total = (uint64_t)W * n;
   uint32_t K = (uint32_t)((total + lanes - 1) / lanes);
   K = (K + 3u) & ~3u;
-  return K < 4 ? 4 : K;
+  if (K < 4) K = 4;
+  // The accumulate kernel is launched as W rows of ceil(ceil(n/K)/64) one-wave workgroups, and all of them must be resident
+  // at once: with even one workgroup more than wave slots, a second round runs that single wave for a whole K entries
+  // (measured, BN254 2^22: c = 15 -> 17 x 241 = 4097 workgroups on 4096 slots, accumulate 6.1 ms instead of ~4.9 ms).
+  // The rounding of the rows can exceed the slots for any n that is not a power of two: grow K until the grid fits.
+  const uint64_t slots = lanes / 64u;
+  while ((uint64_t)W * ((((uint64_t)n + K - 1) / K + 63u) / 64u) > slots && K < 0x7ffffff0u) K += 4u;
+  return K;
 }
 
 static inline int choose_window_bits(uint32_t n, int bits, uint32_t lanes) {
@@ -105,16 +123,16 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   // sort pass A: ~512 partition blocks of at least 2048 scalars; pass B: groups of ~16384 entries (one workgroup
   // sorts a group inside LDS), at most 4096 buckets per group (LDS counters)
   static const uint32_t slenv = getenv("CTT_SORT_SLICE") ? (uint32_t)atoi(getenv("CTT_SORT_SLICE")) : 2048u;
-  uint32_t slice = o.S > 0 ? (uint32_t)o.S : slenv;
-  while (o.S <= 0 && (uint64_t)slice * 512u < n) slice <<= 1;
-  while (o.S <= 0 && slice > 64u && (uint64_t)slice * 64u > n) slice >>= 1;  // small n: at least ~64 partition blocks
+  uint32_t slice = o.S > 0 ? (uint32_t)o.S : plan_partition_slice(n, slenv);
   p.slice = slice;
   p.S = (n + slice - 1) / slice;
   p.jbits = 1;
   while (p.jbits < 31 && (1ull << p.jbits) < n) p.jbits++;
   // groups of ~16384 entries (k_group_sort holds one in LDS), at most 1024 buckets per group, and the packed
   // record (low bucket bits | sign | index) must fit 32 bits
-  static const uint32_t gsz = getenv("CTT_SORT_GROUP") ? (uint32_t)atoi(getenv("CTT_SORT_GROUP")) : 16384u;
+  // (18432, not 16384: a size just above a power of two keeps the group count of that power of two -- 2^22 + 77777 pairs with
+  // 512 groups of 8192 instead of 256 of 16384 sorted in 0.82 ms instead of 0.65 ms; a group may hold 20480 in one sweep)
+  static const uint32_t gsz = getenv("CTT_SORT_GROUP") ? (uint32_t)atoi(getenv("CTT_SORT_GROUP")) : 18432u;
   static const uint32_t capenv = getenv("CTT_SORT_CAP") ? (uint32_t)atoi(getenv("CTT_SORT_CAP")) : 20480u;
   static const uint32_t bigenv = getenv("CTT_SORT_BIG") ? (uint32_t)atoi(getenv("CTT_SORT_BIG")) : 1024u;
   p.cap = capenv;
@@ -208,9 +226,7 @@ static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab
   p.merged = 1;
   p.nent = (uint32_t)((uint64_t)p.Wd * n);
   p.id_stride = ntab;
-  uint32_t slice = o.S > 0 ? (uint32_t)o.S : 2048u;
-  while (o.S <= 0 && (uint64_t)slice * 512u < n) slice <<= 1;
-  while (o.S <= 0 && slice > 64u && (uint64_t)slice * 64u > n) slice >>= 1;
+  uint32_t slice = o.S > 0 ? (uint32_t)o.S : plan_partition_slice(n, 2048u);
   p.slice = slice;
   p.S = (n + slice - 1) / slice;
   p.jbits = 0;   // (the 64-bit partition records of this form hold the whole table row)

@@ -14,7 +14,7 @@ from constantine_amd.synth import synth_scalars  # noqa: E402
 curve, log2n = sys.argv[1], int(sys.argv[2])
 cs = [int(x) for x in sys.argv[3:]] or [0]
 info = CURVES[curve]
-n = 1 << log2n
+n = (1 << log2n) + int(os.environ.get("N_EXTRA", "0"))   # N_EXTRA: sizes that are not a power of two
 eng = DeviceMsm(0)
 d_points = torch.empty((n, info.aff_bytes), dtype=torch.uint8, device="cuda")
 eng.gen_points(curve, 0x5EED0002, n, d_points)
