@@ -396,6 +396,27 @@ def _full_size(name, lg, dev, torch, seed=None):
         dev.set_option("K", 0)
 
 
+@pytest.mark.parametrize("name,n", [("bls12_381_g1", (1 << 17) + 777), ("bls12_381_g1", 3 * (1 << 16) + 1), ("bls12_381_g1", 1000003),
+                                    ("bn254_snarks_g1", (1 << 18) + 12345), ("pallas", 299999)])
+def test_sizes_that_are_not_powers_of_two(name, n, dev, torch_cuda):
+    """The plan's roundings (entries per lane so that the accumulate grid fits the resident wave slots, equal partition
+    blocks, bucket-group count) at sizes that are not powers of two, against the oracle; with the window table as well."""
+    from constantine_amd import CachedBases
+    torch = torch_cuda
+    curve = po.CURVES[name]
+    dp = torch.empty((n, cref.AFF_BYTES[name]), dtype=torch.uint8, device="cuda")
+    dev.gen_points(name, 31337 + n, n, dp)
+    sc = cref.synth_scalars(4000 + n, n, curve.scalar_bits)
+    ds = _to_dev(torch, sc)
+    expect, _ = cref.msm(name, sc, dp.cpu().numpy(), nthreads=NT)
+    assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == bytes(expect)
+    bases = CachedBases(name, dp, ctx=dev.ctx, on_device=True, table=True)
+    try:
+        assert bytes(bases.msm(ds, coord="aff")) == bytes(expect)
+    finally:
+        bases.close()
+
+
 def test_bls12_381_g1_2pow20(dev, torch_cuda):
     """BASELINE config 2: BLS12-381 G1, 2^20 pairs, bit-exact vs the CPU path."""
     _full_size("bls12_381_g1", 20, dev, torch_cuda)
