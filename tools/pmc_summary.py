@@ -45,7 +45,7 @@ def main():
             o.write(f"{k}, {n}, {f:.1f}, {w:.1f}, {int(2 * f * 1024 + w * 1024)}\n")
     acc = next((r for r in rows if "k_accum" in r[0]), None)
     cal_r = next((r for r in rows if r[0].endswith("k_part_count")), None)
-    cal_w = next((r for r in rows if r[0].endswith("k_group_sort")), None)
+    cal_w = next((r for r in rows if "k_group_sort" in r[0]), None)
     doc = {}
     if os.path.exists(out_json):
         try:
