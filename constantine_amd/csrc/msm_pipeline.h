@@ -474,7 +474,11 @@ struct MsmEngine {
     // (the bucket sets are cleared before that wait: the previous MSM read them in its first reduction pass, which is ahead
     // of this point on the main stream, and its tail does not touch them)
     bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
-    bk.tail_wait();
+    // Small MSMs: when the accumulate grid leaves wave slots free (2^16 pairs: 1720 one-wave workgroups on 2048 slots), the
+    // previous tail's narrow passes run next to it, and the wait moves to the start of this MSM's reduction (reduce_buckets),
+    // the first kernel that writes what the tail still reads.
+    const uint64_t accum_waves = (uint64_t)W * ((p.G + 63u) / 64u);
+    if (accum_waves * 64u * 100u > (uint64_t)opt.lanes * 85u) bk.tail_wait();
     bk.stage_begin(sl, ST_ACCUM);
     st.d_buckets = d_buckets;
     st.d_heads = (XYZZ<FD>*)need(heads, (size_t)W * p.G * sizeof(XYZZ<FD>));
@@ -507,6 +511,7 @@ struct MsmEngine {
   void reduce_buckets(int sl, const MsmPlan& p, XYZZ<FD>* d_buckets) {
     Slot& S = slots[sl];
     const uint32_t W = p.W, B = p.B;
+    bk.tail_wait();   // (a no-op unless accumulate_pairs left the previous tail running: small MSMs)
     bk.stage_begin(sl, ST_REDUCE);
     XYZZ<FD>* d_pyr = (XYZZ<FD>*)need(rA[0], (size_t)W * B * sizeof(XYZZ<FD>));
     XYZZ<FD>* d_q = (XYZZ<FD>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<FD>));
@@ -529,7 +534,10 @@ struct MsmEngine {
     // ... unless another MSM of this engine is in flight: then the caller is pipelining, the host tail of this MSM hides
     // under the next MSM's GPU work, and a longer device tail would only delay that MSM's accumulation (measured, BLS12-381
     // G1 2^20: device sums 3.60 ms blocking / 3.26 ms per pipelined step, host sums 3.74 / 3.04)
-    S.host_bits = opt.host_window_sums == 1 || (opt.host_window_sums == 0 && slots[sl ^ 1].busy);
+    // Small MSMs keep the device sums even then: below ~2^13 pairs a step of the GPU is shorter than the host's Horner over
+    // W*c points (measured, two in flight, BLS12-381 G1: 2^10 0.35 ms per MSM with device sums against 0.59 ms with host sums,
+    // 2^13 0.38 / 0.61, 2^14 0.59 / 0.61, 2^15 0.66 / 0.63, 2^17 0.99 / 0.83).
+    S.host_bits = opt.host_window_sums == 1 || (opt.host_window_sums == 0 && slots[sl ^ 1].busy && p.n > 8192u);
     if (!S.host_bits) {
       d_wsum = (XYZZ<FD>*)need(rP[1], (size_t)W * sizeof(XYZZ<FD>));
       bk.template launch_window_sums<FD>(d_out, d_wsum, W, p.c);

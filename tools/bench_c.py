@@ -16,12 +16,14 @@ cs = [int(x) for x in sys.argv[3:]] or [0]
 info = CURVES[curve]
 n = (1 << log2n) + int(os.environ.get("N_EXTRA", "0"))   # N_EXTRA: sizes that are not a power of two
 eng = DeviceMsm(0)
+if os.environ.get("HWS"):
+    eng.set_option("host_window_sums", int(os.environ["HWS"]))   # 0 auto, 1 host, 2 device
 d_points = torch.empty((n, info.aff_bytes), dtype=torch.uint8, device="cuda")
 eng.gen_points(curve, 0x5EED0002, n, d_points)
 d_scal = torch.from_numpy(synth_scalars(0x5EED0003, n, info.scalar_bits)).cuda()
 torch.cuda.synchronize()
 ref = None
-steps = 10 if log2n <= 22 else 4
+steps = 60 if log2n <= 18 else 10 if log2n <= 22 else 4
 for c in cs:
     eng.set_option("c", c)
     eng.enable_timings(False)
