@@ -78,6 +78,19 @@ def msm_table(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, K=0):
     return out, cu
 
 
+def plan(n, bits, lanes, table_c=0, ntab=0):
+    """The engine's plan for n pairs (make_plan / make_table_plan) as a dict."""
+    out = np.zeros(16, dtype=np.uint32)
+    L = lib()
+    L.emu_plan.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
+    L.emu_plan(n, bits, lanes, table_c, ntab, _p(out))
+    return dict(zip(("c", "W", "Wd", "B", "K", "G", "S", "slice", "NG", "gshift", "nent"), (int(x) for x in out)))
+
+
+def table_window_bits(ntab, bits):
+    return lib().emu_table_window_bits(ctypes.c_uint32(ntab), bits)
+
+
 def gen_points(curve, seed, n, first=0):
     out = np.zeros((n, AFF_BYTES[curve]), dtype=np.uint8)
     lib().emu_gen_points(CURVE_ID[curve], seed, first, n, _p(out))

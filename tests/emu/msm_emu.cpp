@@ -319,6 +319,16 @@ int emu_msm_host(int curve, int coef_is_fr, int out_kind, void* r, const void* c
   const EmuOps* o = ops_of(curve);
   return o ? o->msm_host(coef_is_fr, out_kind, r, coefs, points, n, c, chunks) : -1;
 }
+// the plan the engine would make (msm_pipeline.h make_plan / make_table_plan): c, W, Wd, B, K, G, S, slice, NG, gshift, nent
+int emu_plan(uint32_t n, int bits, uint32_t lanes, int table_c, uint32_t ntab, uint32_t* out) {
+  MsmOptions o;
+  o.lanes = lanes;
+  const MsmPlan p = table_c > 0 ? make_table_plan(n, bits, table_c, ntab, o) : make_plan(n, bits, o);
+  out[0] = (uint32_t)p.c; out[1] = (uint32_t)p.W; out[2] = (uint32_t)p.Wd; out[3] = p.B; out[4] = p.K; out[5] = p.G;
+  out[6] = p.S; out[7] = p.slice; out[8] = p.NG; out[9] = p.gshift; out[10] = p.nent;
+  return 0;
+}
+int emu_table_window_bits(uint32_t ntab, int bits) { return choose_table_window_bits(ntab, bits); }
 int emu_msm_table(int curve, int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t ntab, size_t n,
                   int c, int K) {
   const EmuOps* o = ops_of(curve);

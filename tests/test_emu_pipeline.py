@@ -296,3 +296,28 @@ def test_window_table_for_cached_bases(name):
         # all-zero scalars -> neutral
         out, _ = emu.msm_table(name, np.zeros((n, 32), np.uint8), pts, c=4)
         assert _aff(curve, out) is None
+
+
+def test_plan_fits_the_gpu_for_any_size():
+    """The plan's roundings (msm_pipeline.h): the accumulate grid -- W rows of ceil(G/64) one-wave workgroups -- never exceeds
+    the resident wave slots (one workgroup more means a second round of a single wave: measured +28 % on BN254 2^22 at c = 15),
+    the partition blocks are at most 512 + a rounding remainder and all of one size, every entry has a lane; for sizes that are
+    and are not powers of two, both scalar widths, both occupancies, and the window-table form."""
+    rng = random.Random(99)
+    sizes = [1, 2, 63, 64, 65, 1000, 4096, 65536, 65537, 100000, (1 << 17) + 777, 3 << 16, 1000003, 1 << 20, (1 << 20) + 12345,
+             (1 << 22) + 77777, 1 << 24, (1 << 24) + 1, 5 << 22] + [rng.randrange(1, 1 << 25) for _ in range(200)]
+    for n in sizes:
+        for bits, lanes in ((255, 131072), (254, 262144), (255, 65536)):
+            p = emu.plan(n, bits, lanes)
+            assert p["W"] == bits // p["c"] + 1 and p["Wd"] == p["W"] and p["nent"] == n
+            assert p["G"] == -(-n // p["K"]) and p["K"] % 4 == 0
+            assert p["W"] * -(-p["G"] // 64) <= max(lanes // 64, p["W"]), (n, bits, lanes, p)
+            assert p["S"] == -(-n // p["slice"]) and p["S"] <= 520, (n, p)
+            assert p["NG"] <= 4096 and (p["B"] >> p["gshift"]) == p["NG"] and p["B"] // p["NG"] <= 1024
+            c = emu.table_window_bits(n, bits)
+            assert 4 <= c <= 22
+            t = emu.plan(n, bits, lanes, table_c=c, ntab=n)
+            assert t["W"] == 1 and t["Wd"] == bits // c + 1 and t["nent"] == t["Wd"] * n
+            assert -(-t["G"] // 64) <= max(lanes // 64, 1), (n, bits, lanes, t)
+            assert t["G"] == -(-t["nent"] // t["K"])
+            assert t["NG"] <= 16384 and t["B"] // t["NG"] <= 1024
