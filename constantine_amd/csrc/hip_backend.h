@@ -77,21 +77,12 @@ __global__ void __launch_bounds__(ACCUM_BLOCK, (sizeof(XYZZ<F>) > 256 ? 1 : CTT_
   accum_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
 }
 template <class F>
-__global__ void __launch_bounds__(EC_BLOCK) k_merge_tail(MergeArgs<F> a, bool final_) {
-  merge_tail_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, final_);
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_tail(MergeArgs<F> a) {
+  merge_tail_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
 }
 template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_merge_step(MergeArgs<F> a, uint32_t d) {
   merge_step_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, d);
-}
-template <class F>
-__global__ void __launch_bounds__(EC_BLOCK) k_merge_final(MergeArgs<F> a) {
-  merge_final_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
-}
-template <class F>
-__global__ void __launch_bounds__(EC_BLOCK) k_pyr(PyrArgs<F> a, uint32_t ntasks) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < ntasks) pyr_body<F>(a, blockIdx.y, t);
 }
 template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
@@ -192,15 +183,7 @@ __device__ __forceinline__ void xyzz_add_quad(const XYZZ<F>* s1, const XYZZ<F>* 
   }
 }
 
-// --- window sums on the device: S_w = sum_l 2^l O_l + TOP, one quad per window -------------------------------------
-// The bucket reduction leaves c points per window (O_0 .. O_{c-2}: the sums of the buckets whose index has bit l set, and
-// TOP: the sum of all buckets).  Their combination is a Horner over the bits, r = 2r + O_l: a chain of c-1 doublings
-// and c additions.  It used to run on the host together with the Horner over the windows; here one quad per window
-// walks it with the accumulator resident in registers (every lane of the quad holds a full copy): a doubling is 3 rounds
-// of independent products, an addition 4 -- and the host is left with W points and the W*c doublings that join them.
-//   doubling  round 1   V = U^2 (U = 2Y)   XX = X^2         -                -
-//             round 2   Wv = U*V           S = X*V          MM = Mm^2        -              (Mm = 3 XX)
-//             round 3   A = Mm*(S-X3)      Bv = Wv*Y        ZZ3 = V*ZZ       ZZZ3 = Wv*ZZZ  (X3 = MM - 2S, Y3 = A - Bv)
+// --- the accumulator of a quad resident in registers (every lane holds a full copy): the bit Horner of k_reduce_finish ---
 template <class F>
 __device__ __forceinline__ F quad_pick(int role, const F& a, const F& b, const F& c, const F& d) {
   return F::select(role < 2, F::select(role == 0, a, b), F::select(role == 2, c, d));
@@ -250,43 +233,88 @@ __device__ __forceinline__ void xyzz_add_quad_reg(XYZZ<F>& acc, const XYZZ<F>& q
   acc.zz = quad_bcast<2>(T3);
   acc.zzz = quad_bcast<3>(T4);
 }
-// out[w][0..c) -> wsum[w]; one workgroup of 64 lanes per window, the first quad works
-template <class F>
-__global__ void __launch_bounds__(EC_BLOCK) k_window_sums(const XYZZ<F>* out, XYZZ<F>* wsum, int c) {
-  if (threadIdx.x >= 4) return;
-  const int role = (int)threadIdx.x;
-  const XYZZ<F>* o = out + (size_t)blockIdx.x * c;
-  XYZZ<F> r = XYZZ<F>::inf();
-  for (int l = c - 2; l >= 0; l--) {
-    xyzz_dbl_quad_reg<F>(r, role);
-    const XYZZ<F> y = o[l];
-    xyzz_add_quad_reg<F>(r, y, role);
-  }
-  const XYZZ<F> top = o[c - 1];
-  xyzz_add_quad_reg<F>(r, top, role);
-  if (role == 0) wsum[blockIdx.x] = r;
-}
-
-template <class F>
-__global__ void __launch_bounds__(EC_BLOCK) k_pyr_quad(PyrArgs<F> a, uint32_t ntasks) {
-  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t t = lane >> 2;
-  const int role = (int)(lane & 3u);
+// --- bucket reduction in two launches (msm_bodies.h ReduceArgs) ---------------------------------------------------------
+// One pass = a list of independent tasks (*d1 = *s1 + *s2).  The lanes of the workgroup stride over it, one lane per task
+// while the pass is wide, four lanes per task (xyzz_add_quad: 4 products deep instead of 14) once that takes fewer than
+// quad_ratio times the rounds: a round of one-lane additions costs ~10-17 us, a round of four-lane additions ~4.5 us.
+static constexpr int RED_BLOCK = 256;
+template <class F, class Decode>
+__device__ __forceinline__ void reduce_pass(uint32_t ntasks, uint32_t quad_ratio, Decode&& decode) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t rounds1 = (ntasks + nt - 1) / nt, rounds4 = (4u * ntasks + nt - 1) / nt;
   const XYZZ<F>* s1;
   const XYZZ<F>* s2;
   XYZZ<F>* d1;
   XYZZ<F>* d2;
-  const bool live = t < ntasks && pyr_decode<F>(a, blockIdx.y, t, s1, s2, d1, d2);
-  if (!live) return;  // whole quads leave together (t is the same for the four lanes)
-  if (!s2) {
-    if (role == 0) {
-      const XYZZ<F> x = *s1;
-      *d1 = x;
-      if (d2) *d2 = x;
+  if (rounds4 < quad_ratio * rounds1) {
+    const int role = (int)(tid & 3u);
+    for (uint32_t t = tid >> 2; t < ntasks; t += nt >> 2) {   // t is the same for the four lanes of a quad
+      if (!decode(t, s1, s2, d1, d2)) continue;
+      if (!s2) {
+        if (role == 0) reduce_task_run<F>(s1, s2, d1, d2);
+        continue;
+      }
+      xyzz_add_quad<F>(s1, s2, d1, d2, role);
     }
-    return;
+  } else {
+    for (uint32_t t = tid; t < ntasks; t += nt)
+      if (decode(t, s1, s2, d1, d2)) reduce_task_run<F>(s1, s2, d1, d2);
   }
-  xyzz_add_quad<F>(s1, s2, d1, d2, role);
+}
+// level 1: workgroup (j, w) takes block j of window w through its k pyramid passes; the levels and trees of the block live
+// in its own slice of the scratch arrays (written and re-read by this workgroup only: they stay in the XCD's L2)
+template <class F>
+__global__ void __launch_bounds__(RED_BLOCK) k_reduce_blocks(ReduceArgs<F> a) {
+  const uint32_t j = blockIdx.x, w = blockIdx.y;
+  for (int p = 0; p < a.k; p++) {
+    const PyrArgs<F> v = reduce_block_view<F>(a, w, j, p);
+    reduce_pass<F>(pyr_pass_tasks(a.BLK, a.k + 1, p), a.quad_ratio,
+                   [&](uint32_t t, const XYZZ<F>*& s1, const XYZZ<F>*& s2, XYZZ<F>*& d1, XYZZ<F>*& d2) {
+                     return pyr_decode<F>(v, 0, t, s1, s2, d1, d2);
+                   });
+    __syncthreads();
+  }
+}
+// level 2 + bit Horner: one workgroup per window.  The Horner of group g (bits [g*h, g*h + h) of the bucket index, TOP joins
+// group 0) is walked by quad g with the accumulator resident in registers -- every lane of the quad holds a full copy; a
+// doubling is 3 rounds of independent products, an addition 4:
+//   doubling  round 1   V = U^2 (U = 2Y)   XX = X^2         -                -
+//             round 2   Wv = U*V           S = X*V          MM = Mm^2        -              (Mm = 3 XX)
+//             round 3   A = Mm*(S-X3)      Bv = Wv*Y        ZZ3 = V*ZZ       ZZZ3 = Wv*ZZZ  (X3 = MM - 2S, Y3 = A - Bv)
+template <class F>
+__global__ void __launch_bounds__(RED_BLOCK) k_reduce_finish(ReduceArgs<F> a) {
+  const uint32_t w = blockIdx.x;
+  const int c2 = a.c - a.k;
+  for (int s = 0; s < c2 - 1; s++) {
+    reduce_pass<F>(reduce_finish_tasks(a.nb, c2, a.k, s), a.quad_ratio,
+                   [&](uint32_t t, const XYZZ<F>*& s1, const XYZZ<F>*& s2, XYZZ<F>*& d1, XYZZ<F>*& d2) {
+                     return reduce_finish_decode<F>(a, w, s, t, s1, s2, d1, d2);
+                   });
+    __syncthreads();
+  }
+  const uint32_t tid = threadIdx.x;
+  if (tid >= 4u * (uint32_t)a.ngrp) return;
+  const int role = (int)(tid & 3u), g = (int)(tid >> 2);
+  const XYZZ<F>* o = a.out + (size_t)w * a.c;
+  const int lo = g * a.h;
+  int hi = lo + a.h;
+  if (hi > a.c - 1) hi = a.c - 1;
+  XYZZ<F> r = XYZZ<F>::inf();
+  for (int l = hi - 1; l >= lo; l--) {
+    xyzz_dbl_quad_reg<F>(r, role);
+    const XYZZ<F> y = o[l];
+    xyzz_add_quad_reg<F>(r, y, role);
+  }
+  if (g == 0) {
+    const XYZZ<F> top = o[a.c - 1];
+    xyzz_add_quad_reg<F>(r, top, role);
+  }
+  if (role == 0) a.wsum[(size_t)w * a.ngrp + g] = r;
+}
+// end of the head merge: one workgroup per window (msm_bodies.h merge_finish_body)
+template <class F>
+__global__ void __launch_bounds__(RED_BLOCK) k_merge_finish(MergeArgs<F> a, uint32_t first_d) {
+  merge_finish_body<F>(a, blockIdx.x, first_d, threadIdx.x, blockDim.x, []() { __syncthreads(); });
 }
 // head-merge tree step with four lanes per addition (a step has at most G / 2d additions per window)
 template <class F>
@@ -367,19 +395,14 @@ struct HipBackend {
     HIP_CHECK(hipStreamWaitEvent(stream, ev_tail_done, 0));
     tail_pending = false;
   }
-  static uint32_t quad_threshold() {
-    static const uint32_t v = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 24576u;
-    return v;  // measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768
-  }
-  static bool pyr_is_narrow(uint32_t ntasks, uint32_t W) { return (uint64_t)ntasks * W <= quad_threshold(); }
-  // passes with at most this many additions (all windows) go to the tail stream
-  static bool pyr_goes_to_tail(uint32_t ntasks, uint32_t W) {
-    static const uint32_t v = getenv("CTT_HIP_MSM_TAIL") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_TAIL")) : 131072u;  // about what fits under the next MSM's conversion + sort (measured 2^20: 3.34 ms at 24576, 3.30 at 131072; above that the tail queues behind the next accumulation)
-    return (uint64_t)ntasks * W <= v;
-  }
   int num_cu = 256;
-  hipEvent_t ev_begin[2][ST_COUNT], ev_end[2][ST_COUNT];  // per in-flight slot
-  bool ev_used[2][ST_COUNT];
+  // stage events per in-flight slot; a host-pointer MSM runs the first stages once per upload slice (MsmEngine::submit_host):
+  // every slice records its own pair (stage_chunk) and collect_timings adds them up
+  static constexpr int MAX_CHUNKS = 8;
+  hipEvent_t ev_begin[2][ST_COUNT][MAX_CHUNKS], ev_end[2][ST_COUNT][MAX_CHUNKS];
+  uint32_t ev_used[2][ST_COUNT];   // bit i: chunk i recorded
+  int chunk = 0;
+  void stage_chunk(int i) { chunk = i < MAX_CHUNKS ? i : MAX_CHUNKS - 1; }
   hipEvent_t ev_done[2];
   float stage_ms[ST_COUNT];
 
@@ -426,39 +449,36 @@ struct HipBackend {
     hipLaunchKernelGGL(k_iota, grid1(n, 256), dim3(256), 0, stream, entries, n, bucket_start, maxcount);
     HIP_CHECK(hipGetLastError());
   }
-  // small device->host word, overlapped with kernels launched after it
-  uint32_t* h_word = nullptr;
-  hipEvent_t ev_word = nullptr;
-  void fetch_u32_async(const uint32_t* d) {
-    if (!h_word) {
-      HIP_CHECK(hipHostMalloc((void**)&h_word, 64, hipHostMallocDefault));
-      HIP_CHECK(hipEventCreateWithFlags(&ev_word, hipEventDisableTiming));
-    }
-    HIP_CHECK(hipMemcpyAsync(h_word, d, 4, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipEventRecord(ev_word, stream));
-  }
-  uint32_t fetch_u32_wait() {
-    HIP_CHECK(hipEventSynchronize(ev_word));
-    return *h_word;
-  }
   // Stage timing is opt-in (ctt_hip_msm_set_option "timings"): twelve event records per MSM are host time a caller of a
   // small MSM should not pay for a number it does not read.
   bool timing = false;
   void stage_begin(int slot, int s) {
     if (!timing) return;
-    HIP_CHECK(hipEventRecord(ev_begin[slot][s], stream));
-    ev_used[slot][s] = true;
+    if (s == ST_TOTAL) {
+      for (int i = 0; i < ST_COUNT; i++) ev_used[slot][i] = 0;
+      chunk = 0;
+    }
+    const int ch = (s == ST_TOTAL || s == ST_REDUCE) ? 0 : chunk;
+    HIP_CHECK(hipEventRecord(ev_begin[slot][s][ch], stream));
+    ev_used[slot][s] |= 1u << ch;
   }
   void stage_end(int slot, int s) {
-    if (timing) HIP_CHECK(hipEventRecord(ev_end[slot][s], cur()));
+    if (!timing) return;
+    const int ch = (s == ST_TOTAL || s == ST_REDUCE) ? 0 : chunk;
+    HIP_CHECK(hipEventRecord(ev_end[slot][s][ch], cur()));
   }
   // stage times of the MSM that used `slot` (call after its finish())
   void collect_timings(int slot) {
     for (int i = 0; i < ST_COUNT; i++) {
-      if (!timing) stage_ms[i] = 0.f;
-      if (!timing || !ev_used[slot][i]) continue;
-      HIP_CHECK(hipEventSynchronize(ev_end[slot][i]));
-      HIP_CHECK(hipEventElapsedTime(&stage_ms[i], ev_begin[slot][i], ev_end[slot][i]));
+      stage_ms[i] = 0.f;
+      if (!timing) continue;
+      for (int ch = 0; ch < MAX_CHUNKS; ch++) {
+        if (!(ev_used[slot][i] >> ch & 1u)) continue;
+        float ms = 0.f;
+        HIP_CHECK(hipEventSynchronize(ev_end[slot][i][ch]));
+        HIP_CHECK(hipEventElapsedTime(&ms, ev_begin[slot][i][ch], ev_end[slot][i][ch]));
+        stage_ms[i] += ms;
+      }
     }
   }
 
@@ -497,8 +517,8 @@ struct HipBackend {
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
-  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W, bool final_) {
-    hipLaunchKernelGGL(k_merge_tail<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, final_);
+  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W) {
+    hipLaunchKernelGGL(k_merge_tail<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
@@ -512,8 +532,8 @@ struct HipBackend {
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
-  void launch_merge_final(const MergeArgs<F>& a, uint32_t W) {
-    hipLaunchKernelGGL(k_merge_final<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
+  void launch_merge_finish(const MergeArgs<F>& a, uint32_t W, uint32_t first_d) {
+    hipLaunchKernelGGL(k_merge_finish<F>, dim3(W), dim3(RED_BLOCK), 0, stream, a, first_d);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
@@ -521,20 +541,29 @@ struct HipBackend {
     hipLaunchKernelGGL(k_bucket_sum<F>, grid1(set_elems, EC_BLOCK), dim3(EC_BLOCK), 0, stream, sets, nsets, set_elems);
     HIP_CHECK(hipGetLastError());
   }
+  // wave slots of the chip for the reduction kernels (their additions need about as many registers as the accumulation's)
   template <class F>
-  void launch_window_sums(const XYZZ<F>* out, XYZZ<F>* wsum, uint32_t W, int c) {
-    hipLaunchKernelGGL(k_window_sums<F>, dim3(W), dim3(EC_BLOCK), 0, cur(), out, wsum, c);
+  uint32_t reduce_wave_slots() {
+    static uint32_t v = 0;
+    if (!v) {
+      int nb = 0;
+      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_reduce_blocks<F>, 64, 0));
+      v = (uint32_t)(nb < 1 ? 1 : nb) * (uint32_t)num_cu;
+    }
+    return v;
+  }
+  template <class F>
+  void launch_reduce_blocks(const ReduceArgs<F>& a, uint32_t W) {
+    // as many lanes per block as keeps every workgroup resident at once: more lanes = fewer rounds per pass
+    const uint64_t wgs = (uint64_t)a.nb * W, slots = reduce_wave_slots<F>();
+    static const int force = getenv("CTT_HIP_MSM_RED_NT") ? atoi(getenv("CTT_HIP_MSM_RED_NT")) : 0;
+    int nt = force > 0 ? force : wgs * 4u <= slots ? 256 : wgs * 2u <= slots ? 128 : 64;
+    hipLaunchKernelGGL(k_reduce_blocks<F>, dim3(a.nb, W), dim3(nt), 0, cur(), a);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
-  void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
-    // few tasks left: four lanes per addition (the chip is mostly idle, the addition is 3.5x shallower)
-    if (pyr_is_narrow(ntasks, W)) {
-      hipLaunchKernelGGL(k_pyr_quad<F>, grid2(ntasks * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, ntasks);
-      HIP_CHECK(hipGetLastError());
-      return;
-    }
-    hipLaunchKernelGGL(k_pyr<F>, grid2(ntasks, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, ntasks);
+  void launch_reduce_finish(const ReduceArgs<F>& a, uint32_t W) {
+    hipLaunchKernelGGL(k_reduce_finish<F>, dim3(W), dim3(RED_BLOCK), 0, cur(), a);
     HIP_CHECK(hipGetLastError());
   }
 };

@@ -86,37 +86,45 @@ struct Fp64 {
   static inline Fp64 neg(const Fp64& a) { return a.is_zero() ? a : sub(zero(), a); }
   static inline Fp64 cneg(const Fp64& a, bool c) { return c ? neg(a) : a; }
 
-  // product-scanning Montgomery multiplication with a 192-bit column accumulator
+  // Montgomery multiplication, coarsely integrated operand scanning (the reference's shape for the CPU,
+  // limbs_montgomery.nim:268-310), every loop fully unrolled (N is 4 or 6): one row of a*b_i and one row of m*p per step,
+  // each a chain of 64x64->128 multiply-adds whose sum a*b + t + carry cannot overflow 128 bits.  The host tail of an MSM
+  // is one dependent chain of W*c doublings (msm_pipeline.h combine_groups): this routine IS its latency (round 2's
+  // product-scanning form with a 192-bit accumulator took 65 ns per 381-bit product, this one half of that).
   static inline Fp64 mul(const Fp64& a, const Fp64& b) {
     uint64_t p[N];
+#pragma GCC unroll 8
     for (int i = 0; i < N; i++) p[i] = P(i);
     const uint64_t mi = m0inv();
-    uint64_t m[N], t[N];
-    u128 acc = 0;     // low 128 bits
-    uint64_t hi = 0;  // bits 128..191
-    auto mac = [&](uint64_t x, uint64_t y) {
-      u128 pr = (u128)x * y;
-      acc += pr;
-      hi += (acc < pr) ? 1 : 0;
-    };
-    auto shift = [&]() {
-      acc = (acc >> 64) | ((u128)hi << 64);
-      hi = 0;
-    };
-    for (int k = 0; k < N; k++) {
-      for (int i = 0; i <= k; i++) mac(a.l[i], b.l[k - i]);
-      for (int i = 0; i < k; i++) mac(m[i], p[k - i]);
-      m[k] = (uint64_t)acc * mi;
-      mac(m[k], p[0]);
-      shift();
+    uint64_t t[N + 1];
+#pragma GCC unroll 8
+    for (int i = 0; i <= N; i++) t[i] = 0;
+#pragma GCC unroll 8
+    for (int i = 0; i < N; i++) {
+      const uint64_t bi = b.l[i];
+      u128 c = 0;
+#pragma GCC unroll 8
+      for (int j = 0; j < N; j++) {
+        c += (u128)a.l[j] * bi + t[j];
+        t[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      u128 top = (u128)t[N] + (uint64_t)c;      // t has N+2 words for a moment: the extra bit is `over`
+      t[N] = (uint64_t)top;
+      const uint64_t over = (uint64_t)(top >> 64);
+      const uint64_t m = t[0] * mi;
+      c = ((u128)m * p[0] + t[0]) >> 64;
+#pragma GCC unroll 8
+      for (int j = 1; j < N; j++) {
+        c += (u128)m * p[j] + t[j];
+        t[j - 1] = (uint64_t)c;
+        c >>= 64;
+      }
+      top = (u128)t[N] + (uint64_t)c;
+      t[N - 1] = (uint64_t)top;
+      t[N] = over + (uint64_t)(top >> 64);
     }
-    for (int k = N; k < 2 * N; k++) {
-      for (int i = k - N + 1; i < N; i++) mac(a.l[i], b.l[k - i]);
-      for (int i = k - N + 1; i < N; i++) mac(m[i], p[k - i]);
-      t[k - N] = (uint64_t)acc;
-      shift();
-    }
-    return reduce_once(t, (uint64_t)acc);
+    return reduce_once(t, t[N]);
   }
   static inline Fp64 sqr(const Fp64& a) { return mul(a, a); }
 

@@ -352,14 +352,23 @@ struct MergeArgs {
   uint32_t B, K, G;
 };
 
-// heads[g+1] += tails[g]: a tail is the first piece of a straddling bucket, the next lane's head continues it
-// `final_` (no bucket spans more than two lanes, i.e. every chain of heads has length one): the sum is the bucket.
+// longest possible chain of heads: a bucket of m entries spans at most floor((m-1)/K)+1 lanes (maxcount = the largest
+// bucket, written by the sort before the accumulation starts: the merge kernels read it on the device, the host never waits)
 template <class F>
-CTT_HD void merge_tail_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, bool final_) {
+CTT_HD uint32_t merge_chain_bound(const MergeArgs<F>& a) {
+  const uint32_t mc = *a.maxcount;
+  return mc ? (mc - 1) / a.K + 1 : 0;
+}
+
+// heads[g+1] += tails[g]: a tail is the first piece of a straddling bucket, the next lane's head continues it.
+// When no bucket spans more than two lanes (every chain of heads has length one) the sum is the bucket.
+template <class F>
+CTT_HD void merge_tail_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
   if (g + 1 >= a.G) return;
   const uint64_t slot = (uint64_t)w * a.G + g;
   const uint32_t b = a.tkey[slot];
   if (b == KEY_NONE) return;
+  const bool final_ = merge_chain_bound<F>(a) <= 1;
   XYZZ<F> h = a.heads[slot + 1];
   XYZZ<F> t = a.tails[slot];
   XYZZ<F> r = xyzz_add_inl<F>(h, t);
@@ -404,6 +413,22 @@ CTT_HD void merge_final_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
   a.buckets[(uint64_t)w * a.B + b] = a.heads[slot];
 }
 
+// End of the merge, one workgroup per window (the GPU kernel strides its lanes over g and puts a workgroup barrier where
+// `sync` is called): nothing to do when the tail merge wrote the buckets (chains of length one); otherwise the tree steps
+// d = first_d, 2 first_d, ... that the wide step kernels launched before it did not cover -- the host enqueues as many wide
+// steps as an ordinary digit distribution needs WITHOUT knowing the largest bucket, an adversarial input (all scalars equal:
+// chains of G heads) finishes its tree here -- and then the chain heads become the buckets.
+template <class F, class Sync>
+CTT_HD void merge_finish_body(const MergeArgs<F>& a, uint32_t w, uint32_t first_d, uint32_t lane, uint32_t nlanes, Sync&& sync) {
+  const uint32_t chain = merge_chain_bound<F>(a);
+  if (chain <= 1) return;
+  for (uint32_t d = first_d; d < chain; d <<= 1) {
+    for (uint32_t g = lane; g < a.G; g += nlanes) merge_step_body<F>(a, w, g, d);
+    sync();
+  }
+  for (uint32_t g = lane; g < a.G; g += nlanes) merge_final_body<F>(a, w, g);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Sum of the bucket sets of a host-pointer MSM uploaded in slices (MsmEngine::submit_host): sets[0][i] += sets[k][i].
 // ---------------------------------------------------------------------------------------------
@@ -442,6 +467,7 @@ struct PyrArgs {
   uint32_t B;
   int c;
   int p;                   // pass index, 0 .. c-2
+  uint32_t out_stride;     // elements between out[l] and out[l+1] (1 = contiguous; the block-local form writes columns)
 };
 
 template <class F>
@@ -471,7 +497,8 @@ CTT_HD bool pyr_decode(const PyrArgs<F>& a, uint32_t w, uint32_t t, const XYZZ<F
                        XYZZ<F>*& d2) {
   const uint32_t B = a.B;
   const int c = a.c, p = a.p;
-  XYZZ<F>* out = a.out + (uint64_t)w * c;
+  XYZZ<F>* out = a.out + (uint64_t)w * c * a.out_stride;
+  const uint64_t os = a.out_stride;
   s1 = nullptr;
   s2 = nullptr;
   d1 = nullptr;
@@ -484,7 +511,7 @@ CTT_HD bool pyr_decode(const PyrArgs<F>& a, uint32_t w, uint32_t t, const XYZZ<F
     s1 = src + 2 * t;
     s2 = src + 2 * t + 1;
     d1 = a.pyr + (uint64_t)w * B + (B - (B >> p)) + t;  // level p+1
-    if (p + 1 == c - 1) d2 = out + (c - 1);             // TOP
+    if (p + 1 == c - 1) d2 = out + (uint64_t)(c - 1) * os;  // TOP
   } else if (t - na < nb) {
     const uint32_t u = t - na;
     const XYZZ<F>* src = pyr_level<F>(a, w, p);
@@ -492,10 +519,10 @@ CTT_HD bool pyr_decode(const PyrArgs<F>& a, uint32_t w, uint32_t t, const XYZZ<F
       s1 = src + 2 * u + 1;
       s2 = src + 2 * (u + L / 2) + 1;
       d1 = a.q + (uint64_t)w * (B / 2) + (B / 2 - (B >> (p + 1))) + u;
-      if (L / 2 == 1) d2 = out + p;
+      if (L / 2 == 1) d2 = out + (uint64_t)p * os;
     } else {
       s1 = src + 1;   // single odd element: O_p is a copy
-      d1 = out + p;
+      d1 = out + (uint64_t)p * os;
     }
   } else {
     uint32_t u = t - na - nb;                       // (c) halve the trees started in earlier passes
@@ -510,7 +537,7 @@ CTT_HD bool pyr_decode(const PyrArgs<F>& a, uint32_t w, uint32_t t, const XYZZ<F
         s1 = qd + u;
         s2 = qd + u + nc;
         d1 = qd + u;
-        if (nc == 1) d2 = out + l;
+        if (nc == 1) d2 = out + (uint64_t)l * os;
         break;
       }
       u -= nc;
@@ -536,6 +563,106 @@ CTT_HD void pyr_body(const PyrArgs<F>& a, uint32_t w, uint32_t t) {
   *d1 = x;
   if (d2) *d2 = x;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same reduction in TWO launches (round 3).  Pass p of the pyramid only combines elements of one aligned block of
+// 2^(p+1) buckets, so an aligned block of BLK = 2^k buckets can be taken through its first k passes by ONE workgroup
+// (workgroup barriers between the passes instead of kernel boundaries):
+//
+//   level 1 (reduce_block_*)   per block j of window w: the block-local O_0 .. O_{k-1} (sums of the block's buckets whose
+//                              LOCAL index has bit l set) and the block total T_j, written as columns cols[w][l][j]
+//   level 2 (reduce_finish_*)  per window, one workgroup: O_l = sum_j cols[l][j] for l < k (k plain trees over the nb = B/BLK
+//                              blocks), and the pyramid over the block totals T_j gives O_k .. O_{c-2} and TOP -- bit l >= k
+//                              of a bucket index is bit l-k of its block index.  Both have log2(nb) passes.
+//                              Then the Horner over the bits, split into groups of h bits (window_group_sum_body): the
+//                              device returns ngrp = ceil((c-1)/h) partial sums per window and the host's Horner over the
+//                              windows (which has to walk W*c doublings anyway) joins them (combine_groups, msm_pipeline.h).
+// k = 0 (few buckets): level 2 alone, its pyramid runs over the buckets themselves.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+struct ReduceArgs {
+  const XYZZ<F>* buckets;  // [W][B]
+  XYZZ<F>* pyr;            // [W][B]        scratch: pyramid levels of the blocks
+  XYZZ<F>* q;              // [W][B/2]      scratch: odd-element trees of the blocks
+  XYZZ<F>* cols;           // [W][k+1][nb]  block results: O_0 .. O_{k-1} of every block, then the block totals
+  XYZZ<F>* pyr2;           // [W][nb]       scratch of level 2 (pyramid over the block totals)
+  XYZZ<F>* q2;             // [W][nb/2+1]
+  XYZZ<F>* out;            // [W][c]        O_0 .. O_{c-2}, TOP  (nb == 1: level 1 writes it directly, cols == out)
+  XYZZ<F>* wsum;           // [W][ngrp]     partial Horner sums of the window
+  uint32_t B, BLK, nb;     // buckets per window, per block, blocks per window (BLK * nb == B; k == 0: BLK = 1)
+  int c, k, h, ngrp;       // window bits; log2(BLK); bits per Horner group; groups per window
+  uint32_t quad_ratio;     // GPU: a pass runs with four lanes per addition while that takes fewer than quad_ratio x the rounds
+};
+
+// level 1: the pyramid passes of block j of window w seen as a pyramid of its own (pyr_decode with w = 0)
+template <class F>
+CTT_HD PyrArgs<F> reduce_block_view(const ReduceArgs<F>& a, uint32_t w, uint32_t j, int p) {
+  PyrArgs<F> v;
+  const uint64_t off = (uint64_t)w * a.B + (uint64_t)j * a.BLK;
+  v.buckets = a.buckets + off;
+  v.pyr = a.pyr + off;
+  v.q = a.q + off / 2;
+  v.out = a.cols + (uint64_t)w * (uint64_t)(a.k + 1) * a.nb + j;
+  v.out_stride = a.nb;
+  v.B = a.BLK;
+  v.c = a.k + 1;
+  v.p = p;
+  return v;
+}
+// level 2: the pyramid over the block totals of window w (the buckets themselves when k == 0)
+template <class F>
+CTT_HD PyrArgs<F> reduce_finish_view(const ReduceArgs<F>& a, uint32_t w, int s) {
+  PyrArgs<F> v;
+  v.buckets = a.k == 0 ? a.buckets + (uint64_t)w * a.B : a.cols + ((uint64_t)w * (uint64_t)(a.k + 1) + (uint64_t)a.k) * a.nb;
+  v.pyr = a.pyr2 + (uint64_t)w * a.nb;
+  v.q = a.q2 + (uint64_t)w * (a.nb / 2 + 1);
+  v.out = a.out + (uint64_t)w * a.c + a.k;
+  v.out_stride = 1;
+  v.B = a.nb;
+  v.c = a.c - a.k;
+  v.p = s;
+  return v;
+}
+// tasks of level-2 pass s: the pyramid's, then k column trees with (nb >> s) / 2 additions each
+CTT_HD uint32_t reduce_finish_tasks(uint32_t nb, int c2, int k, int s) {
+  return pyr_pass_tasks(nb, c2, s) + (uint32_t)k * ((nb >> s) / 2);
+}
+template <class F>
+CTT_HD bool reduce_finish_decode(const ReduceArgs<F>& a, uint32_t w, int s, uint32_t t, const XYZZ<F>*& s1, const XYZZ<F>*& s2,
+                                 XYZZ<F>*& d1, XYZZ<F>*& d2) {
+  const uint32_t npyr = pyr_pass_tasks(a.nb, a.c - a.k, s);
+  if (t < npyr) {
+    const PyrArgs<F> v = reduce_finish_view<F>(a, w, s);
+    return pyr_decode<F>(v, 0, t, s1, s2, d1, d2);
+  }
+  const uint32_t half = (a.nb >> s) / 2;
+  const uint32_t u = t - npyr;
+  s1 = nullptr;
+  s2 = nullptr;
+  d1 = nullptr;
+  d2 = nullptr;
+  if (half == 0 || u >= (uint32_t)a.k * half) return false;
+  const uint32_t l = u / half, i = u - l * half;
+  XYZZ<F>* col = a.cols + ((uint64_t)w * (uint64_t)(a.k + 1) + l) * a.nb;
+  s1 = col + i;
+  s2 = col + i + half;
+  d1 = col + i;
+  if (half == 1) d2 = a.out + (uint64_t)w * a.c + l;
+  return true;
+}
+// one task: *d1 (and *d2) = *s1 + *s2, or a copy (the GPU's four-lane form is in hip_backend.h)
+template <class F>
+CTT_HD void reduce_task_run(const XYZZ<F>* s1, const XYZZ<F>* s2, XYZZ<F>* d1, XYZZ<F>* d2) {
+  XYZZ<F> x = *s1;
+  if (s2) {
+    XYZZ<F> y = *s2;
+    x = xyzz_add_inl<F>(x, y);
+  }
+  *d1 = x;
+  if (d2) *d2 = x;
+}
+// groups of the bit Horner: group g covers bits [g*h, min((g+1)*h, c-1)) of the bucket index
+CTT_HD int horner_groups(int c, int h) { return c > 1 ? (c - 1 + h - 1) / h : 1; }
 
 // ---------------------------------------------------------------------------------------------
 // sum_reduce (ec_shortweierstrass_batch_ops.nim:649-663): every point belongs to ONE bucket, so the bucket

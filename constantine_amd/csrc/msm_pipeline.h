@@ -31,6 +31,11 @@ struct MsmPlan {
   uint32_t merged;     // 1 = window-table form
   uint32_t nent;       // entries per bucket set: n, or Wd*n
   uint32_t id_stride;  // table rows per window (the cached bases' length; a call may use a prefix)
+  // bucket reduction in two launches (msm_bodies.h ReduceArgs): blocks of 2^rk buckets, rnb blocks per window
+  int rk;
+  uint32_t rnb;
+  int h, ngrp;         // bit Horner: bits per group, groups per window (the device returns W*ngrp partial sums)
+  int merge_steps;     // wide head-merge tree steps enqueued without knowing the largest bucket (plan_merge_steps)
 };
 
 struct MsmOptions {
@@ -38,9 +43,11 @@ struct MsmOptions {
   int K = 0;          // entries per lane (0 = choose from resident lanes)
   int S = 0;          // sort: scalars per partition block (0 = choose)
   uint32_t lanes = 196608;  // resident lanes of the accumulate kernel (set by the backend)
-  int host_window_sums = 0;  // where the Horner over the bit sums of a window runs: 0 = on the device unless the caller is
-                             // pipelining MSMs (see reduce_buckets), 1 = always on the host (the round-1 arrangement),
-                             // 2 = always on the device
+  int host_window_sums = 0;  // legacy spelling of horner_bits: 1 = 1 bit per group (the whole bit Horner on the host),
+                             // 2 = one group per window (the whole bit Horner on the device), 0 = horner_bits decides
+  int horner_bits = 0;       // bits per group of the bit Horner the device runs (0 = choose: 4); see plan_reduce
+  int reduce_block = 0;      // log2 of the buckets one workgroup of the first reduction launch takes (0 = choose)
+  int quad_ratio = 0;        // reduction passes run four lanes per addition while that needs < quad_ratio x the rounds (0 = 3)
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -105,6 +112,46 @@ static inline int choose_window_bits(uint32_t n, int bits, uint32_t lanes) {
   return bc;
 }
 
+// Shape of the bucket reduction (msm_bodies.h ReduceArgs).  Few buckets (B <= 512): the one-workgroup-per-window launch
+// does everything.  Otherwise a first launch takes blocks of 2^rk >= 256 buckets each, at most 256 blocks per window, so that
+// the per-window workgroup of the second launch is left with <= 256 block totals and rk column trees over <= 256 elements.
+static inline void plan_reduce(MsmPlan& p, const MsmOptions& o) {
+  int lb = 0;
+  while ((1u << lb) < p.B) lb++;   // B = 2^lb
+  int rk = 0;
+  if (p.B > 512u) {
+    rk = o.reduce_block > 0 ? o.reduce_block : 8;
+    if (rk < 1) rk = 1;
+    while (lb - rk > 8) rk++;      // nb <= 256
+    if (rk > lb) rk = lb;
+  }
+  p.rk = rk;
+  p.rnb = p.B >> rk;
+  int h = o.host_window_sums == 1 ? 1 : o.host_window_sums == 2 ? p.c : o.horner_bits > 0 ? o.horner_bits : 4;
+  if (h > p.c) h = p.c;
+  p.h = h;
+  p.ngrp = horner_groups(p.c, h);
+}
+// Wide head-merge tree steps to enqueue: enough for the largest bucket an ordinary (uniform) digit distribution produces --
+// lambda entries per bucket on average, in the top window nent / 2^(top-1) (its digits only reach 2^(top-1) buckets; a
+// window table adds that to every bucket's share) -- with a margin of 6 sigma + 8; whatever an unusual input needs on top
+// of that is done by the merge-finish launch (one workgroup per window, msm_bodies.h merge_finish_body).
+static inline int plan_merge_steps(const MsmPlan& p, int bits) {
+  const double lam = (double)p.nent / (double)p.B;
+  const int top = bits - (p.Wd - 1) * p.c;
+  const double topb = top > 1 ? (double)(1u << (top - 1)) : 1.0;
+  double heavy = (double)p.n / topb;
+  if (p.merged) heavy += lam;
+  double m = heavy > lam ? heavy : lam;
+  double sd = 1.0;
+  while (sd * sd < m) sd += 1.0;
+  m += 6.0 * sd + 8.0;
+  double chain = (m - 1.0) / (double)p.K + 1.0;
+  int steps = 0;
+  while (chain > 1.0 && steps < 31) { chain *= 0.5; steps++; }
+  return steps;
+}
+
 static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   MsmPlan p;
   p.n = n;
@@ -162,6 +209,8 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   p.merged = 0;
   p.nent = n;
   p.id_stride = 0;
+  plan_reduce(p, o);
+  p.merge_steps = plan_merge_steps(p, bits);
   return p;
 }
 
@@ -247,45 +296,40 @@ static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab
   if (K < 4) K = 4;
   p.K = K;
   p.G = (p.nent + K - 1) / K;
+  plan_reduce(p, o);
+  p.merge_steps = plan_merge_steps(p, bits);
   return p;
 }
 
 // Window combine (ec_multi_scalar_mul.nim:250-254; _parallel.nim:199-203), in two parts.
-// On the device, fused with the last step of the bucket reduction: per window the reduction leaves O_0..O_{c-2} (sum of
-// the buckets whose index has bit l set) and TOP (sum of all buckets); window sum S_w = sum_l 2^l O_l + TOP
-// (window_sum_body, one quad per window on the GPU).  On the host: result = sum_w 2^(c*w) S_w, a Horner whose W*c
-// doublings form one dependent chain -- 0.6 us per doubling on a CPU core against 3.6 us for four GPU lanes.
+// On the device, fused into the second launch of the bucket reduction: per window the reduction leaves O_0..O_{c-2} (sum of
+// the buckets whose index has bit l set) and TOP (sum of all buckets); the window sum is S_w = sum_l 2^l O_l + TOP.  The
+// bits are cut into groups of h: P_{w,g} = sum_{l in group g} 2^(l - g*h) O_l (+ TOP in group 0), one quad of lanes per group
+// (window_group_sum_body is what a quad computes) -- a chain of h-1 doublings instead of c-2.  On the host: the Horner over
+// the windows, result = sum_w 2^(c*w) sum_g 2^(g*h) P_{w,g}: its W*c doublings are one dependent chain whatever h is (0.25 us
+// per doubling on a CPU core against 5 us for four GPU lanes), the groups only add ngrp - 1 additions per window to it.
 template <class F>
-CTT_HD XYZZ<F> window_sum_body(const XYZZ<F>* ow, int c) {
+CTT_HD XYZZ<F> window_group_sum_body(const XYZZ<F>* ow, int c, int h, int g) {
+  const int lo = g * h;
+  int hi = lo + h;
+  if (hi > c - 1) hi = c - 1;
   XYZZ<F> r = XYZZ<F>::inf();
-  for (int l = c - 2; l >= 0; l--) {
+  for (int l = hi - 1; l >= lo; l--) {
     r = xyzz_dbl<F>(r);
     xyzz_add<F>(r, ow[l]);
   }
-  xyzz_add<F>(r, ow[c - 1]);
+  if (g == 0) xyzz_add<F>(r, ow[c - 1]);
   return r;
 }
-// both Horners in one chain, for the c points per window as the bucket reduction leaves them (host_window_sums): the
-// doublings of the bit Horner are the doublings of the window Horner, W*c in total
 template <class F>
-static inline XYZZ<F> combine_windows_bits(const XYZZ<F>* o, int W, int c) {
+static inline XYZZ<F> combine_groups(const XYZZ<F>* s, int W, int c, int h, int ngrp) {
   XYZZ<F> r = XYZZ<F>::inf();
   for (int w = W - 1; w >= 0; w--) {
-    const XYZZ<F>* ow = o + (size_t)w * c;
-    for (int l = c - 1; l >= 0; l--) {
-      r = xyzz_dbl<F>(r);
-      if (l <= c - 2) xyzz_add<F>(r, ow[l]);
+    for (int g = ngrp - 1; g >= 0; g--) {
+      const int nd = g == ngrp - 1 ? c - g * h : h;
+      for (int l = 0; l < nd; l++) r = xyzz_dbl<F>(r);
+      xyzz_add<F>(r, s[(size_t)w * ngrp + g]);
     }
-    xyzz_add<F>(r, ow[c - 1]);
-  }
-  return r;
-}
-template <class F>
-static inline XYZZ<F> combine_windows(const XYZZ<F>* s, int W, int c) {
-  XYZZ<F> r = XYZZ<F>::inf();
-  for (int w = W - 1; w >= 0; w--) {
-    for (int l = 0; l < c; l++) r = xyzz_dbl<F>(r);
-    xyzz_add<F>(r, s[w]);
   }
   return r;
 }
@@ -304,11 +348,11 @@ struct MsmEngine {
 
   // grow-only workspace
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf part, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcount, cpoints, totals, gbase;
+  Buf part, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], rC, rS[2], scal, maxcount, cpoints, totals, gbase;
 
   explicit MsmEngine(BK& b) : bk(b) {}
   ~MsmEngine() {
-    Buf* all[] = {&part, &gbase, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount, &cpoints, &totals};
+    Buf* all[] = {&part, &gbase, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &rC, &rS[0], &rS[1], &scal, &maxcount, &cpoints, &totals};
     for (Buf* b : all) if (b->p) bk.free(b->p);
     for (Slot& sl : slots) if (sl.hraw) bk.free_host(sl.hraw);
   }
@@ -331,7 +375,6 @@ struct MsmEngine {
     MsmPlan plan;
     bool busy = false;
     bool empty = false;   // len == 0
-    bool host_bits = false;  // the slot's buffer holds c points per window (MsmOptions::host_window_sums)
     void* hraw = nullptr; // pinned host buffer for the device output
     size_t hcap = 0;
   };
@@ -391,7 +434,7 @@ struct MsmEngine {
   // ---- the stages of one MSM ---------------------------------------------------------------------------------------
   // Stage 1 (per MSM, or per chunk of a host-pointer MSM): scalars -> Booth digits -> entries sorted by bucket ->
   // bucket sums of these pairs in `d_buckets` (heads/tails of the runs that straddle lane ranges still to be merged).
-  // Ends with the accumulate kernel enqueued; the largest bucket is on its way to the host (merge_buckets needs it).
+  // Ends with the accumulate kernel enqueued.
   struct Staged {
     uint32_t* d_bstart;
     uint32_t* d_maxcount;
@@ -463,8 +506,7 @@ struct MsmEngine {
     st.d_maxcount = (uint32_t*)need(maxcount, 256);
     bk.memset0(st.d_maxcount, 8);
     sa.bstart = st.d_bstart; sa.entries = d_entries; sa.maxcount = st.d_maxcount;
-    bk.launch_digits_sort(sa);
-    bk.fetch_u32_async(st.d_maxcount);  // largest bucket: read back while the accumulation runs
+    bk.launch_digits_sort(sa);   // (leaves the largest bucket in d_maxcount[0]: the merge kernels read it there)
     bk.stage_end(sl, ST_SORT);
 
     // The previous MSM's tail (narrow reduction passes + result copy on the backend's second stream) has had this MSM's
@@ -491,75 +533,72 @@ struct MsmEngine {
     return st;
   }
 
-  // Stage 2: partial sums of the buckets that straddle lane ranges.  Waits (host) for the largest bucket of stage 1:
-  // a bucket of m entries spans at most floor((m-1)/K)+1 heads, the tree over such a chain takes log2 steps.  With chains
-  // of length one -- the common case, no bucket larger than K -- the tail merge writes the buckets itself.
+  // Stage 2: partial sums of the buckets that straddle lane ranges.  A bucket of m entries spans at most floor((m-1)/K)+1
+  // heads, the tree over such a chain takes log2 steps; with chains of length one -- the common case, no bucket larger than
+  // K -- the tail merge writes the buckets itself.  The largest bucket is known on the DEVICE (the sort leaves it in
+  // d_maxcount before the accumulation starts) and the kernels decide there: the host enqueues the steps an ordinary digit
+  // distribution needs (MsmPlan::merge_steps) plus the finishing launch that covers everything else, and never waits
+  // (rounds 1-2 read the word back in the middle of submit: a host round-trip per MSM, 0.1 ms of a 0.7 ms step at 2^16).
   void merge_buckets(int sl, const MsmPlan& p, const Staged& st) {
     bk.stage_begin(sl, ST_MERGE);
     MergeArgs<FD> ma{st.d_bstart, st.d_buckets, st.d_heads, st.d_tails, st.d_hkey, st.d_tkey, st.d_maxcount, p.B, p.K, p.G};
-    const uint32_t mc = bk.fetch_u32_wait();
-    const uint32_t chain = mc ? (mc - 1) / p.K + 1 : 0;
-    bk.template launch_merge_tail<FD>(ma, p.W, chain <= 1);
-    if (chain > 1) {
-      for (uint32_t d = 1; d < chain; d <<= 1) bk.template launch_merge_step<FD>(ma, p.W, d);
-      bk.template launch_merge_final<FD>(ma, p.W);
-    }
+    bk.template launch_merge_tail<FD>(ma, p.W);
+    uint32_t d = 1;
+    for (int i = 0; i < p.merge_steps && d < p.G; i++, d <<= 1) bk.template launch_merge_step<FD>(ma, p.W, d);
+    bk.template launch_merge_finish<FD>(ma, p.W, d);
     bk.stage_end(sl, ST_MERGE);
   }
 
-  // Stage 3: bucket reduction (c-1 pyramid passes), window sums, and their copy to the slot's pinned buffer.
+  // Stage 3: bucket reduction (two launches), bit Horner in groups, and the copy of the W*ngrp partial sums to the slot's
+  // pinned buffer.
   void reduce_buckets(int sl, const MsmPlan& p, XYZZ<FD>* d_buckets) {
     Slot& S = slots[sl];
-    const uint32_t W = p.W, B = p.B;
+    const size_t W = p.W, B = p.B, nb = p.rnb;
     bk.tail_wait();   // (a no-op unless accumulate_pairs left the previous tail running: small MSMs)
     bk.stage_begin(sl, ST_REDUCE);
-    XYZZ<FD>* d_pyr = (XYZZ<FD>*)need(rA[0], (size_t)W * B * sizeof(XYZZ<FD>));
-    XYZZ<FD>* d_q = (XYZZ<FD>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<FD>));
-    XYZZ<FD>* d_out = (XYZZ<FD>*)need(rP[0], (size_t)W * p.c * sizeof(XYZZ<FD>));
-    // The narrow passes at the end (and the result copy) move to the backend's tail stream: they are latency-bound
-    // and the next MSM's conversion and sort fit underneath them (the tail_wait() before the accumulation also orders
-    // the previous tail before this MSM's first write to the pyramid buffers).
-    bool forked = false;
-    for (int pass = 0; pass <= p.c - 2; pass++) {
-      PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass};
-      const uint32_t ntasks = pyr_pass_tasks(B, p.c, pass);
-      if (!forked && pass > 0 && bk.pyr_goes_to_tail(ntasks, W)) {
-        bk.tail_begin();
-        forked = true;
-      }
-      bk.template launch_pyr<FD>(pa, W, ntasks);
-    }
-    // the window sums (Horner over the c points of every window) complete the device part of the combine
-    XYZZ<FD>* d_wsum = d_out;
-    // ... unless another MSM of this engine is in flight: then the caller is pipelining, the host tail of this MSM hides
-    // under the next MSM's GPU work, and a longer device tail would only delay that MSM's accumulation (measured, BLS12-381
-    // G1 2^20: device sums 3.60 ms blocking / 3.26 ms per pipelined step, host sums 3.74 / 3.04)
-    // Small MSMs keep the device sums even then: below ~2^13 pairs a step of the GPU is shorter than the host's Horner over
-    // W*c points (measured, two in flight, BLS12-381 G1: 2^10 0.35 ms per MSM with device sums against 0.59 ms with host sums,
-    // 2^13 0.38 / 0.61, 2^14 0.59 / 0.61, 2^15 0.66 / 0.63, 2^17 0.99 / 0.83).
-    S.host_bits = opt.host_window_sums == 1 || (opt.host_window_sums == 0 && slots[sl ^ 1].busy && p.n > 8192u);
-    if (!S.host_bits) {
-      d_wsum = (XYZZ<FD>*)need(rP[1], (size_t)W * sizeof(XYZZ<FD>));
-      bk.template launch_window_sums<FD>(d_out, d_wsum, W, p.c);
-    }
+    ReduceArgs<FD> ra;
+    ra.buckets = d_buckets;
+    ra.pyr = p.rk ? (XYZZ<FD>*)need(rA[0], W * B * sizeof(XYZZ<FD>)) : nullptr;
+    ra.q = p.rk ? (XYZZ<FD>*)need(rA[1], W * (B / 2 + 1) * sizeof(XYZZ<FD>)) : nullptr;
+    ra.out = (XYZZ<FD>*)need(rP[0], W * p.c * sizeof(XYZZ<FD>));
+    ra.cols = (p.rk && nb > 1) ? (XYZZ<FD>*)need(rC, W * (size_t)(p.rk + 1) * nb * sizeof(XYZZ<FD>)) : ra.out;
+    ra.pyr2 = (XYZZ<FD>*)need(rS[0], W * nb * sizeof(XYZZ<FD>));
+    ra.q2 = (XYZZ<FD>*)need(rS[1], W * (nb / 2 + 1) * sizeof(XYZZ<FD>));
+    ra.wsum = (XYZZ<FD>*)need(rP[1], W * (size_t)p.ngrp * sizeof(XYZZ<FD>));
+    ra.B = p.B;
+    ra.BLK = 1u << p.rk;
+    ra.nb = p.rnb;
+    ra.c = p.c;
+    ra.k = p.rk;
+    ra.h = p.h;
+    ra.ngrp = p.ngrp;
+    ra.quad_ratio = opt.quad_ratio > 0 ? (uint32_t)opt.quad_ratio : 3u;
+    // first launch: the blocks (throughput-bound, stays on the main stream)
+    if (p.rk) bk.template launch_reduce_blocks<FD>(ra, p.W);
+    // second launch: one workgroup per window -- latency-bound, as is the result copy: they move to the backend's tail
+    // stream and the next MSM's conversion and sort run underneath them (the tail_wait() before the accumulation also
+    // orders the previous tail before this MSM's first write to the reduction buffers)
+    bk.tail_begin();
+    bk.template launch_reduce_finish<FD>(ra, p.W);
     bk.stage_end(sl, ST_REDUCE);
 
-    const size_t bytes = (size_t)W * (S.host_bits ? p.c : 1) * sizeof(XYZZ<FD>);
+    const size_t bytes = W * (size_t)p.ngrp * sizeof(XYZZ<FD>);
     if (bytes > S.hcap) {
       if (S.hraw) bk.free_host(S.hraw);
       S.hraw = bk.alloc_host(bytes);
       S.hcap = bytes;
     }
-    bk.d2h_async(sl, S.hraw, d_wsum, bytes);
+    bk.d2h_async(sl, S.hraw, ra.wsum, bytes);
     bk.stage_end(sl, ST_TOTAL);
-    if (forked) bk.tail_end();
+    bk.tail_end();
   }
 
   int claim_slot(uint32_t n) {
-    const int sl = next_slot;
+    int sl = next_slot;
+    if (slots[sl].busy) sl ^= 1;    // tickets may be finished in any order: take whichever slot is free
     Slot& S = slots[sl];
     if (S.busy) return -1;  // two MSMs in flight already: the caller finishes the oldest first (C ABI: error code)
-    next_slot ^= 1;
+    next_slot = sl ^ 1;
     S.busy = true;
     S.empty = (n == 0);  // len == 0 is UB upstream; we return the neutral
     return sl;
@@ -644,12 +683,17 @@ struct MsmEngine {
     MsmPlan p_prev = p0;
     for (uint32_t i = 0; i < nch; i++) {
       const uint32_t start = bound[i], cnt = bound[i + 1] - bound[i];
+      bk.stage_chunk((int)i);   // stage events of this slice (the stage times of the call are the sums over its slices)
       uint32_t* d_c = (uint32_t*)d_stage_coefs + (size_t)start * 8;
       Affine<F>* d_p = (Affine<F>*)d_stage_points + start;
       bk.h2d(d_c, (const char*)h_coefs + (size_t)start * 32, (size_t)cnt * 32);                   // the GPU works on slice i-1 meanwhile
       bk.h2d(d_p, (const char*)h_points + (size_t)start * sizeof(Affine<F>), (size_t)cnt * sizeof(Affine<F>));
       bk.h2d_done();                                                                              // main stream waits for the copies
-      if (i > 0) merge_buckets(sl, p_prev, st_prev);   // slice i-1's merge goes in front of slice i's kernels (shared workspace)
+      if (i > 0) {   // slice i-1's merge goes in front of slice i's kernels (shared workspace)
+        bk.stage_chunk((int)i - 1);
+        merge_buckets(sl, p_prev, st_prev);
+        bk.stage_chunk((int)i);
+      }
       const MsmPlan p = make_plan(cnt, C::BITS, o);
       void* d_conv = kConvert ? (void*)((char*)d_conv_all + (size_t)start * gather_stride<FD>()) : nullptr;
       st_prev = accumulate_pairs(sl, p, d_c, coef_is_fr, d_p, nullptr, d_conv, d_sets + (size_t)i * set);
@@ -679,11 +723,10 @@ struct MsmEngine {
     bk.d2h_wait(sl);
     const MsmPlan& p = S.plan;
     const XYZZ<FD>* raw = (const XYZZ<FD>*)S.hraw;
-    const size_t cnt = (size_t)p.W * (S.host_bits ? p.c : 1);
+    const size_t cnt = (size_t)p.W * p.ngrp;
     std::vector<XYZZ<HF>> sums(cnt);
     for (size_t i = 0; i < cnt; i++) sums[i] = xyzz_to_host<FD>(raw[i]);
-    if (S.host_bits) return combine_windows_bits<HF>(sums.data(), p.W, p.c);
-    return combine_windows<HF>(sums.data(), p.W, p.c);
+    return combine_groups<HF>(sums.data(), p.W, p.c, p.h, p.ngrp);
   }
 
   bool in_flight(int sl) const { return sl >= 0 && sl < 2 && slots[sl].busy; }
@@ -725,9 +768,10 @@ struct MsmEngine {
     AccumArgs<FD> aa{d_entries, d_bstart, d_points, point_stride, d_buckets, d_heads, d_tails, d_hkey, d_tkey, n, 1, K, G};
     bk.template launch_accum<FD>(aa, 1);
     MergeArgs<FD> ma{d_bstart, d_buckets, d_heads, d_tails, d_hkey, d_tkey, d_maxcount, 1, K, G};
-    bk.template launch_merge_tail<FD>(ma, 1, false);
-    for (uint32_t d = 1; d < G; d <<= 1) bk.template launch_merge_step<FD>(ma, 1, d);
-    bk.template launch_merge_final<FD>(ma, 1);
+    bk.template launch_merge_tail<FD>(ma, 1);
+    uint32_t d = 1;
+    for (; d < G; d <<= 1) bk.template launch_merge_step<FD>(ma, 1, d);
+    bk.template launch_merge_finish<FD>(ma, 1, d);
     XYZZ<FD> raw;
     bk.d2h_sync(&raw, d_buckets, sizeof(raw));
     return xyzz_to_host<FD>(raw);

@@ -32,6 +32,7 @@ def lib():
         L.emu_msm_table.argtypes = [i32, i32, i32, vp, vp, vp, sz, sz, i32, i32]
         L.emu_sum_reduce.argtypes = [i32, i32, vp, vp, sz, i32]
         L.emu_batch_affine.argtypes = [i32, i32, vp, vp, sz, i32]
+        L.emu_msm_slots.argtypes = [i32, vp, vp, vp, sz]
         _lib = L
     return _lib
 
@@ -50,6 +51,16 @@ def msm(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, K=0, S=0):
     rc = lib().emu_msm(CURVE_ID[curve], int(coef_is_fr), out_kind, _p(out), _p(coefs), _p(points), n, c, K, S, _p(plan))
     assert rc == 0
     return out, plan
+
+
+def msm_slots(curve, coefs, points):
+    """Three MSMs over the same input with tickets finished out of order (submit A, complete B, complete C, finish A).
+    Returns (three affine results, refused submits)."""
+    coefs = np.ascontiguousarray(coefs, dtype=np.uint8)
+    points = np.ascontiguousarray(points, dtype=np.uint8)
+    out = np.zeros((3, AFF_BYTES[curve]), dtype=np.uint8)
+    refused = lib().emu_msm_slots(CURVE_ID[curve], _p(out), _p(coefs), _p(points), coefs.shape[0])
+    return out, refused
 
 
 def msm_host(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, chunks=0):

@@ -24,7 +24,7 @@ struct EmuBackend {
   void tail_begin() {}
   void tail_end() {}
   void tail_wait() {}
-  static bool pyr_goes_to_tail(uint32_t, uint32_t) { return false; }
+  void stage_chunk(int) {}
   void d2h_sync(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void h2d(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void h2d_done() {}
@@ -35,9 +35,6 @@ struct EmuBackend {
   void launch_iota(uint32_t* entries, uint32_t n, uint32_t* bstart, uint32_t* maxcount) {
     for (uint32_t j = 0; j < (n ? n : 1); j++) iota_body(entries, n, bstart, maxcount, j);
   }
-  uint32_t word = 0;
-  void fetch_u32_async(const uint32_t* d) { word = *d; }
-  uint32_t fetch_u32_wait() { return word; }
   void stage_begin(int, int) {}
   void stage_end(int, int) {}
 
@@ -119,25 +116,46 @@ struct EmuBackend {
     for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) accum_body<F>(a, w, g);
   }
   template <class F>
-  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W, bool final_) {
-    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_tail_body<F>(a, w, g, final_);
+  void launch_merge_tail(const MergeArgs<F>& a, uint32_t W) {
+    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_tail_body<F>(a, w, g);
   }
   template <class F>
   void launch_merge_step(const MergeArgs<F>& a, uint32_t W, uint32_t d) {
     for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_step_body<F>(a, w, g, d);
   }
   template <class F>
-  void launch_merge_final(const MergeArgs<F>& a, uint32_t W) {
-    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_final_body<F>(a, w, g);
+  void launch_merge_finish(const MergeArgs<F>& a, uint32_t W, uint32_t first_d) {
+    // one "workgroup" of one lane per window: the lane strides over all g, the barrier is a no-op
+    for (uint32_t w = 0; w < W; w++) merge_finish_body<F>(a, w, first_d, 0, 1, []() {});
+  }
+  // the two launches of the bucket reduction: passes in order, the tasks of a pass in any order (a pass reads only what
+  // earlier passes wrote, except the in-place halvings q[t] += q[t+n] and col[i] += col[i+half] on disjoint elements)
+  template <class F>
+  void launch_reduce_blocks(const ReduceArgs<F>& a, uint32_t W) {
+    for (uint32_t w = 0; w < W; w++)
+      for (uint32_t j = 0; j < a.nb; j++)
+        for (int p = 0; p < a.k; p++) {
+          const PyrArgs<F> v = reduce_block_view<F>(a, w, j, p);
+          const uint32_t nt = pyr_pass_tasks(a.BLK, a.k + 1, p);
+          for (uint32_t t = 0; t < nt; t++) {
+            const XYZZ<F>* s1; const XYZZ<F>* s2; XYZZ<F>* d1; XYZZ<F>* d2;
+            if (pyr_decode<F>(v, 0, t, s1, s2, d1, d2)) reduce_task_run<F>(s1, s2, d1, d2);
+          }
+        }
   }
   template <class F>
-  void launch_window_sums(const XYZZ<F>* out, XYZZ<F>* wsum, uint32_t W, int c) {
-    for (uint32_t w = 0; w < W; w++) wsum[w] = window_sum_body<F>(out + (size_t)w * c, c);
-  }
-  template <class F>
-  void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
-    // a pass reads only what earlier passes wrote, except the in-place halving q[t] += q[t+n] (disjoint t)
-    for (uint32_t w = 0; w < W; w++) for (uint32_t t = 0; t < ntasks; t++) pyr_body<F>(a, w, t);
+  void launch_reduce_finish(const ReduceArgs<F>& a, uint32_t W) {
+    const int c2 = a.c - a.k;
+    for (uint32_t w = 0; w < W; w++) {
+      for (int s = 0; s < c2 - 1; s++) {
+        const uint32_t nt = reduce_finish_tasks(a.nb, c2, a.k, s);
+        for (uint32_t t = 0; t < nt; t++) {
+          const XYZZ<F>* s1; const XYZZ<F>* s2; XYZZ<F>* d1; XYZZ<F>* d2;
+          if (reduce_finish_decode<F>(a, w, s, t, s1, s2, d1, d2)) reduce_task_run<F>(s1, s2, d1, d2);
+        }
+      }
+      for (int g = 0; g < a.ngrp; g++) a.wsum[(size_t)w * a.ngrp + g] = window_group_sum_body<F>(a.out + (size_t)w * a.c, a.c, a.h, g);
+    }
   }
 };
 
@@ -159,10 +177,21 @@ struct EmuOps {
   int (*dev_info)(int* lb, int* nl);
   int (*sum_reduce)(int out_kind, void* r, const void* points, size_t n, int K);
   void (*batch_affine)(int src_kind, void* dst, const void* src, size_t n, int K);
+  // ticket order: submit A, then two complete MSMs B and C while A is outstanding, then finish A; r3 = 3 affine results;
+  // returns the number of submits that were refused (0 expected)
+  int (*msm_slots)(void* r3, const void* coefs, const void* points, size_t n);
 };
 
 #ifdef EMU_CURVE
 #include "generators.h"
+
+// test knobs of the reduction shape (tests/test_emu_pipeline.py sets them per case)
+static void emu_env_options(MsmOptions& o) {
+  const char* s;
+  if ((s = getenv("EMU_HORNER_BITS"))) o.horner_bits = atoi(s);
+  if ((s = getenv("EMU_REDUCE_BLOCK"))) o.reduce_block = atoi(s);
+  if ((s = getenv("EMU_HOST_WINDOW_SUMS"))) o.host_window_sums = atoi(s);
+}
 
 template <class C>
 struct EmuCurve {
@@ -176,6 +205,7 @@ struct EmuCurve {
     eng.opt.K = K;
     eng.opt.S = S;
     eng.opt.lanes = 4096;
+    emu_env_options(eng.opt);
     // exercise both in-flight slots: submit twice, finish in order
     // K < 0 in the test harness means: go through the cached-base path (prepare_bases + submit against it)
     void* prepared = nullptr;
@@ -199,6 +229,7 @@ struct EmuCurve {
     MsmEngine<C, EmuBackend> eng(bk);
     eng.opt.c = c;
     eng.opt.lanes = 4096;
+    emu_env_options(eng.opt);
     std::vector<unsigned char> sc(n * 32 + 64), sp(n * sizeof(Affine<F>) + 64);
     int s0 = eng.submit_host(coefs, coef_is_fr != 0, points, (uint32_t)n, sc.data(), sp.data(), chunks);
     auto res = eng.finish(s0);
@@ -211,6 +242,7 @@ struct EmuCurve {
     MsmEngine<C, EmuBackend> eng(bk);
     eng.opt.K = K;
     eng.opt.lanes = 4096;
+    emu_env_options(eng.opt);
     int cu = 0;
     void* tab = eng.prepare_table((const Affine<F>*)points, (uint32_t)ntab, c, &cu);
     int s0 = eng.submit((const uint32_t*)coefs, coef_is_fr != 0, nullptr, (uint32_t)n, tab, cu, (uint32_t)ntab);
@@ -267,8 +299,29 @@ struct EmuCurve {
     BatchAffineArgs<F> a{(const F*)src, (Affine<F>*)dst, (uint32_t)n, src_kind, (uint32_t)K};
     for (uint32_t lane = 0; (uint64_t)lane * K < n; lane++) batch_affine_body<F>(a, lane);
   }
+  static int msm_slots(void* r3, const void* coefs, const void* points, size_t n) {
+    EmuBackend bk;
+    MsmEngine<C, EmuBackend> eng(bk);
+    eng.opt.lanes = 4096;
+    using HF = typename MsmEngine<C, EmuBackend>::HF;
+    const size_t ab = sizeof(Affine<F>);
+    int refused = 0;
+    const int a = eng.submit((const uint32_t*)coefs, false, (const Affine<F>*)points, (uint32_t)n);
+    const int b = eng.submit((const uint32_t*)coefs, false, (const Affine<F>*)points, (uint32_t)n);
+    if (a < 0 || b < 0) return 100;
+    write_result<HF>((char*)r3 + ab, eng.finish(b), OUT_AFF);
+    const int c = eng.submit((const uint32_t*)coefs, false, (const Affine<F>*)points, (uint32_t)n);   // slot of B is free, A's is not
+    if (c < 0) refused++; else write_result<HF>((char*)r3 + 2 * ab, eng.finish(c), OUT_AFF);
+    const int d = eng.submit((const uint32_t*)coefs, false, (const Affine<F>*)points, (uint32_t)n);
+    const int e = d >= 0 ? eng.submit((const uint32_t*)coefs, false, (const Affine<F>*)points, (uint32_t)n) : -1;
+    if (d < 0) refused++;
+    if (e >= 0) refused += 10;   // A and D are outstanding: a third ticket must be refused
+    if (d >= 0) eng.finish(d);
+    write_result<HF>(r3, eng.finish(a), OUT_AFF);
+    return refused;
+  }
   static const EmuOps* ops() {
-    static const EmuOps o = {msm, msm_host, msm_table, gen, fop, fop_dev, dev_info, sum_reduce, batch_affine};
+    static const EmuOps o = {msm, msm_host, msm_table, gen, fop, fop_dev, dev_info, sum_reduce, batch_affine, msm_slots};
     return &o;
   }
 };
@@ -359,6 +412,10 @@ int emu_batch_affine(int curve, int src_kind, void* dst, const void* src, size_t
   if (!o) return -1;
   o->batch_affine(src_kind, dst, src, n, K);
   return 0;
+}
+int emu_msm_slots(int curve, void* r3, const void* coefs, const void* points, size_t n) {
+  const EmuOps* o = ops_of(curve);
+  return o ? o->msm_slots(r3, coefs, points, n) : -1;
 }
 int emu_dev_field_info(int curve, int* lb, int* nl) {
   const EmuOps* o = ops_of(curve);

@@ -298,6 +298,43 @@ def test_window_table_for_cached_bases(name):
         assert _aff(curve, out) is None
 
 
+def test_reduction_shapes_and_horner_groups(monkeypatch):
+    """The two-launch bucket reduction (msm_bodies.h ReduceArgs) for every block size -- one block per window, blocks of 2
+    buckets, the automatic 256 -- and the bit Horner cut into groups of 1, 2, 3, 4, 7 bits or a single group (the legacy
+    host_window_sums spellings included): the same element whatever the shape."""
+    name = "bn254_snarks_g1"
+    n = 400
+    pts = cref.gen_points(name, 901, n)
+    sc = cref.synth_scalars(902, n, 254)
+    expect, _ = cref.msm(name, sc, pts)
+    for c in (2, 4, 9, 10, 11, 12, 14):
+        for rb, hb in ((0, 0), (1, 1), (3, 2), (5, 3), (8, 7), (c - 1, 30), (30, 4)):
+            monkeypatch.setenv("EMU_REDUCE_BLOCK", str(rb))
+            monkeypatch.setenv("EMU_HORNER_BITS", str(hb))
+            out, plan = emu.msm(name, sc, pts, c=c, K=8)
+            assert bytes(out) == bytes(expect), (c, rb, hb)
+    monkeypatch.delenv("EMU_HORNER_BITS")
+    monkeypatch.delenv("EMU_REDUCE_BLOCK")
+    for hws in (1, 2):
+        monkeypatch.setenv("EMU_HOST_WINDOW_SUMS", str(hws))
+        out, _ = emu.msm(name, sc, pts, c=11, K=8)
+        assert bytes(out) == bytes(expect), hws
+
+
+def test_tickets_finished_out_of_order():
+    """Two slots per engine: with ticket A outstanding, blocking calls B and C must both be served (the free slot is
+    taken whichever it is), a third outstanding ticket is refused, and A still finishes correctly afterwards."""
+    name = "bls12_381_g1"
+    n = 90
+    pts = cref.gen_points(name, 911, n)
+    sc = cref.synth_scalars(912, n, 255)
+    expect, _ = cref.msm(name, sc, pts)
+    out, refused = emu.msm_slots(name, sc, pts)
+    assert refused == 0
+    for i in range(3):
+        assert bytes(out[i]) == bytes(expect), i
+
+
 def test_plan_fits_the_gpu_for_any_size():
     """The plan's roundings (msm_pipeline.h): the accumulate grid -- W rows of ceil(G/64) one-wave workgroups -- never exceeds
     the resident wave slots (one workgroup more means a second round of a single wave: measured +28 % on BN254 2^22 at c = 15),

@@ -323,6 +323,59 @@ def test_window_sizes_and_lane_spans(dev, torch_cuda):
         dev.set_option("S", 0)
 
 
+def test_reduction_shapes_horner_groups_and_merge_without_host_wait(dev, torch_cuda):
+    """Round 3: the bucket reduction is two launches (blocks of 2^rb buckets, then one workgroup per window with the bit
+    Horner cut into groups of hb bits) and the head merge decides on the device how far its tree goes.  Same element for
+    every block size / group size, for uniform digits and for the adversarial inputs whose head chains are far longer than
+    the steps the plan enqueues (all scalars equal; a quarter of them equal)."""
+    torch = torch_cuda
+    name = "bls12_381_g1"
+    n = 60000
+    pts = cref.gen_points(name, 191, n)
+    sc = cref.synth_scalars(192, n, 255)
+    sc_eq = np.tile(sc[:1], (n, 1))
+    sc_q = sc.copy()
+    sc_q[::4] = sc[1]
+    dp = _to_dev(torch, pts)
+    try:
+        for label, s in (("uniform", sc), ("all equal", sc_eq), ("quarter equal", sc_q)):
+            expect = bytes(cref.msm(name, s, pts, nthreads=NT)[0])
+            ds = _to_dev(torch, s)
+            for c, rb, hb, K in ((0, 0, 0, 0), (13, 4, 1, 0), (13, 12, 3, 8), (16, 0, 2, 0), (16, 10, 15, 0), (9, 0, 4, 4), (11, 1, 8, 0),
+                                 (15, 7, 5, 12)):
+                dev.set_option("c", c)
+                dev.set_option("K", K)
+                dev.set_option("reduce_block", rb)
+                dev.set_option("horner_bits", hb)
+                assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (label, c, rb, hb, K, dev.last_plan())
+            for qr in (1, 100):   # never / always four lanes per addition in the reduction passes
+                dev.set_option("quad_ratio", qr)
+                dev.set_option("c", 14)
+                assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (label, "quad_ratio", qr)
+            dev.set_option("quad_ratio", 0)
+    finally:
+        for k in ("c", "K", "reduce_block", "horner_bits", "quad_ratio"):
+            dev.set_option(k, 0)
+
+
+def test_tickets_finished_out_of_order(dev, torch_cuda):
+    """with one ticket outstanding, blocking calls must keep working (whichever slot is free is taken)."""
+    torch = torch_cuda
+    name = "vesta"
+    n = 3000
+    pts = cref.gen_points(name, 195, n)
+    sc = cref.synth_scalars(196, n, 255)
+    expect = bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
+    ds, dp = _to_dev(torch, sc), _to_dev(torch, pts)
+    a = dev.submit(name, ds, dp, n)
+    for _ in range(3):
+        assert bytes(dev.msm(name, ds, dp, n)) == expect      # B, C, D while A is outstanding
+    b = dev.submit(name, ds, dp, n)
+    assert bytes(dev.finish(b)) == expect                      # newer ticket first
+    assert bytes(dev.msm(name, ds, dp, n)) == expect
+    assert bytes(dev.finish(a)) == expect
+
+
 @pytest.mark.parametrize("n", [16385, 40000, 100003, (1 << 20) + 7])
 def test_sizes_around_the_sort_group_boundaries(dev, torch_cuda, n):
     """Pair counts that are not powers of two (ragged last partition block, groups of uneven size)."""
