@@ -173,6 +173,9 @@ CTT_HD void acc_shift(Acc3& acc) {
 // Fp
 // ---------------------------------------------------------------------------------------------
 template <class PP>
+struct ModInv;   // modinv.h (included at the end of this file)
+
+template <class PP>
 struct Fp {
   using Params = PP;
   static constexpr int N = PP::N;
@@ -369,8 +372,17 @@ struct Fp {
     return mul(a, r2);
   }
 
-  // a^(p-2).  Same value as the reference's inv_vartime (finite_fields.nim:386-396); inv(0) = 0.
+  // 1/a (inv(0) = 0): same value as the reference's inv_vartime (finite_fields.nim:386-396).  Division steps on the plain
+  // words of the residue (modinv.h) give (aR)^-1; one Montgomery product with R^3 makes that a^-1 R.
   CTT_HD static Fp inv(const Fp& a) {
+    Fp t, r3;
+    ModInv<PP>::inv_words(a.l, t.l);
+#pragma unroll
+    for (int i = 0; i < N; i++) r3.l[i] = PP::R3[i];
+    return mul(t, r3);
+  }
+  // a^(p-2): rounds 1-2's inversion, kept as the cross-check of the one above (tests) and for the cost table in DESIGN.md
+  CTT_HD static Fp inv_fermat(const Fp& a) {
     Fp r = one();
     for (int i = 32 * N - 1; i >= 0; i--) {
       r = sqr(r);
@@ -425,3 +437,5 @@ struct Fp2 {
 };
 
 }  // namespace ctt
+
+#include "modinv.h"

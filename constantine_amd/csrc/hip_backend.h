@@ -410,7 +410,13 @@ struct HipBackend {
 
   void* alloc(size_t b) {
     void* p = nullptr;
-    HIP_CHECK(hipMalloc(&p, b));
+    const hipError_t e = hipMalloc(&p, b);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {   // recoverable: the call fails, the process lives
+      (void)hipGetLastError();
+      fprintf(stderr, "[ctt_msm_hip] out of device memory: hipMalloc of %zu bytes failed\n", b);
+      throw OutOfDeviceMemory{b};
+    }
+    HIP_CHECK(e);
     return p;
   }
   void free(void* p) { HIP_CHECK(hipFree(p)); }

@@ -128,13 +128,16 @@ struct Fp64 {
   }
   static inline Fp64 sqr(const Fp64& a) { return mul(a, a); }
 
-  static inline Fp64 inv(const Fp64& a) {  // a^(p-2)
-    Fp64 r = one();
-    for (int i = 64 * N - 1; i >= 0; i--) {
-      r = sqr(r);
-      if ((PP::PM2[i >> 5] >> (i & 31)) & 1u) r = mul(r, a);
-    }
-    return r;
+  // 1/a by division steps on the 32-bit words of the residue (modinv.h): (aR)^-1, then one product with R^3.
+  // (a^(p-2) cost 17-25 us of every MSM's host tail; this is ~3 us)
+  static inline Fp64 inv(const Fp64& a) {
+    uint32_t w[2 * N], o[2 * N];
+    memcpy(w, a.l, sizeof(w));
+    ModInv<PP>::inv_words(w, o);
+    Fp64 t, r3;
+    memcpy(t.l, o, sizeof(o));
+    for (int i = 0; i < N; i++) r3.l[i] = (uint64_t)PP::R3[2 * i] | ((uint64_t)PP::R3[2 * i + 1] << 32);
+    return mul(t, r3);
   }
 };
 

@@ -13,6 +13,10 @@
 
 namespace ctt {
 
+// thrown by a backend's alloc() when the device is out of memory: the engine releases what it holds for the call and the
+// C ABI turns it into the call's error value (NULL / -1) where there is one (round 2 aborted the process)
+struct OutOfDeviceMemory { size_t bytes; };
+
 struct MsmPlan {
   uint32_t n;
   int c, W;
@@ -359,8 +363,10 @@ struct MsmEngine {
   void* need(Buf& b, size_t bytes) {
     if (bytes > b.cap) {
       if (b.p) bk.free(b.p);
+      b.p = nullptr;
+      b.cap = 0;
       size_t cap = bytes + bytes / 8 + 256;
-      b.p = bk.alloc(cap);
+      b.p = bk.alloc(cap);   // may throw OutOfDeviceMemory: the buffer is then simply empty
       b.cap = cap;
     }
     return b.p;
@@ -408,13 +414,26 @@ struct MsmEngine {
   // base descriptor (constantine-halo2-zal/src/lib.rs:68-95), which upstream passes through unchanged.
   // Returns the records (caller-owned, free with bk.free); c = 0 chooses the window bits.  *c_out = the bits used.
   void* prepare_table(const Affine<F>* d_points_in, uint32_t n, int c, int* c_out) {
-    if (c <= 0 || !table_plan_fits(n, C::BITS, c)) c = choose_table_window_bits(n, C::BITS);
+    // c above what choose_table_window_bits searches (22: 2^21 buckets, 16384 bucket groups of the sort) is not a plan the
+    // sort can run, c < 2 is no window at all: take the automatic choice instead
+    if (c < 2 || c > 22 || !table_plan_fits(n, C::BITS, c)) c = choose_table_window_bits(n, C::BITS);
     *c_out = c;
     if (n == 0 || c == 0) return nullptr;
     const int Wd = C::BITS / c + 1;
     const size_t stride = kConvert ? (size_t)gather_stride<FD>() : sizeof(Affine<F>);
-    char* tab = (char*)bk.alloc((size_t)Wd * n * stride);
-    Affine<F>* lvl[2] = {(Affine<F>*)bk.alloc((size_t)n * sizeof(Affine<F>)), (Affine<F>*)bk.alloc((size_t)n * sizeof(Affine<F>))};
+    char* tab = nullptr;
+    Affine<F>* lvl[2] = {nullptr, nullptr};
+    try {
+      tab = (char*)bk.alloc((size_t)Wd * n * stride);
+      lvl[0] = (Affine<F>*)bk.alloc((size_t)n * sizeof(Affine<F>));
+      lvl[1] = (Affine<F>*)bk.alloc((size_t)n * sizeof(Affine<F>));
+    } catch (const OutOfDeviceMemory&) {
+      // (bits/c + 1) x the records did not fit: no table, the caller keeps plain records (c_out = 0)
+      if (tab) bk.free(tab);
+      if (lvl[0]) bk.free(lvl[0]);
+      *c_out = 0;
+      return nullptr;
+    }
     const Affine<F>* cur = d_points_in;
     for (int w = 0; w < Wd; w++) {
       if (w > 0) {
@@ -614,16 +633,27 @@ struct MsmEngine {
     const MsmPlan p = table_c > 0 ? make_table_plan(n, C::BITS, table_c, table_n, opt) : make_plan(n, C::BITS, opt);
     slots[sl].plan = p;
     last_plan = p;
-    bk.stage_begin(sl, ST_TOTAL);
-    void* d_converted = nullptr;
-    if constexpr (kConvert) {
-      if (!d_prepared) d_converted = need(cpoints, (size_t)n * gather_stride<FD>());
+    try {
+      bk.stage_begin(sl, ST_TOTAL);
+      void* d_converted = nullptr;
+      if constexpr (kConvert) {
+        if (!d_prepared) d_converted = need(cpoints, (size_t)n * gather_stride<FD>());
+      }
+      XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(buckets, (size_t)p.W * p.B * sizeof(XYZZ<FD>));
+      const Staged st = accumulate_pairs(sl, p, d_coefs, coef_is_fr, d_points_in, d_prepared, d_converted, d_buckets);
+      merge_buckets(sl, p, st);
+      reduce_buckets(sl, p, d_buckets);
+    } catch (const OutOfDeviceMemory&) {
+      return release_slot(sl);
     }
-    XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(buckets, (size_t)p.W * p.B * sizeof(XYZZ<FD>));
-    const Staged st = accumulate_pairs(sl, p, d_coefs, coef_is_fr, d_points_in, d_prepared, d_converted, d_buckets);
-    merge_buckets(sl, p, st);
-    reduce_buckets(sl, p, d_buckets);
     return sl;
+  }
+  // a submit that ran out of device memory: what it enqueued so far runs to its end on buffers that stay valid (a buffer is
+  // only ever freed by need(), and hipFree waits for the device); the slot is free again.  Returns the error value -2.
+  int release_slot(int sl) {
+    slots[sl].busy = false;
+    next_slot = sl;
+    return -2;
   }
 
   // One MSM on HOST-resident inputs (what the Constantine C symbols hand over), uploaded in `chunks` slices of pairs so
@@ -671,6 +701,7 @@ struct MsmEngine {
     for (uint32_t i = 0; i < nch; i++) largest = bound[i + 1] - bound[i] > largest ? bound[i + 1] - bound[i] : largest;
     MsmOptions o = opt;
     if (o.c <= 0) o.c = choose_window_bits(n, C::BITS, o.lanes);  // one window size for the whole MSM
+    try {
     bk.stage_begin(sl, ST_TOTAL);
     const MsmPlan p0 = make_plan(largest, C::BITS, o);   // the largest slice sizes the workspace
     const size_t set = (size_t)p0.W * p0.B;
@@ -707,6 +738,9 @@ struct MsmEngine {
     last_plan = plast;
     last_chunks = nch;
     reduce_buckets(sl, plast, d_sets);
+    } catch (const OutOfDeviceMemory&) {
+      return release_slot(sl);
+    }
     return sl;
   }
   uint32_t last_chunks = 1;

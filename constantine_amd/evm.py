@@ -82,20 +82,31 @@ def _jac_to_affine(F2: bool, r: np.ndarray):
     return X * zi * zi % _P, Y * zi * zi * zi % _P
 
 
-def _validate(curve: str, pts: np.ndarray, on_curve):
-    """The reference validates the pairs in order, each point fully (on the curve, then in the subgroup:
-    ethereum_evm_precompiles.nim fromRawCoords) before the next one: the status is that of the FIRST offending point.
-    The subgroup checks ([r]P = neutral) of all points run as one GPU launch."""
+_OK, _TOO_LARGE, _OFF_CURVE = 0, 1, 2
+
+
+def _fp_or_none(b64: bytes):
+    try:
+        return _fp(b64)
+    except EvmError:
+        return None
+
+
+def _validate(curve: str, pts: np.ndarray, parse):
+    """The reference handles the pairs in order, each point fully (coordinates below the modulus, on the curve, in the
+    subgroup: ethereum_evm_precompiles.nim fromRawCoords) before the next one: the status is that of the FIRST offending
+    pair.  `parse[i]` is the host-side verdict on pair i (_OK, _TOO_LARGE, _OFF_CURVE; rows of pairs that did not parse are
+    the neutral point).  The subgroup checks ([r]P = neutral) of all points run as one GPU launch."""
     from .msm import subgroup_check
-    in_subgroup = subgroup_check(curve, pts) if all(on_curve) else None
-    for i, oc in enumerate(on_curve):
-        if not oc:
-            # an earlier point outside the subgroup comes first: check the points in front of this one
-            if i and not subgroup_check(curve, pts[:i]).all():
-                raise EvmError(CttEVMStatus.cttEVM_PointNotInSubgroup)
-            raise EvmError(CttEVMStatus.cttEVM_PointNotOnCurve)
-    if not in_subgroup.all():
+    bad = next((i for i, st in enumerate(parse) if st != _OK), None)
+    if bad is None:
+        if not subgroup_check(curve, pts).all():
+            raise EvmError(CttEVMStatus.cttEVM_PointNotInSubgroup)
+        return
+    # an earlier point outside the subgroup comes first: check the points in front of the offending pair
+    if bad and not subgroup_check(curve, pts[:bad]).all():
         raise EvmError(CttEVMStatus.cttEVM_PointNotInSubgroup)
+    raise EvmError(CttEVMStatus.cttEVM_IntLargerThanModulus if parse[bad] == _TOO_LARGE else CttEVMStatus.cttEVM_PointNotOnCurve)
 
 
 def _scalars(recs, off):
@@ -107,13 +118,18 @@ def eth_evm_bls12381_g1msm(inputs: bytes) -> bytes:
     if len(inputs) == 0 or len(inputs) % 160 != 0:
         raise EvmError(CttEVMStatus.cttEVM_InvalidInputSize)
     recs = [inputs[i:i + 160] for i in range(0, len(inputs), 160)]
-    rows, on_curve = [], []
+    rows, parse = [], []
     for rec in recs:
-        x, y = _fp(rec[0:64]), _fp(rec[64:128])
-        on_curve.append((x == 0 and y == 0) or (y * y - x * x * x - 4) % _P == 0)
-        rows.append(_mont(x) + _mont(y))
+        x, y = _fp_or_none(rec[0:64]), _fp_or_none(rec[64:128])
+        if x is None or y is None:
+            parse.append(_TOO_LARGE)
+            rows.append(bytes(96))
+            continue
+        on_curve = (x == 0 and y == 0) or (y * y - x * x * x - 4) % _P == 0
+        parse.append(_OK if on_curve else _OFF_CURVE)
+        rows.append(_mont(x) + _mont(y) if on_curve else bytes(96))
     pts = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), 96)
-    _validate("bls12_381_g1", pts, on_curve)
+    _validate("bls12_381_g1", pts, parse)
     res = _jac_to_affine(False, multiScalarMul_vartime("bls12_381_g1", _scalars(recs, 128), pts, coord="jac"))
     if res is None:
         return bytes(128)
@@ -124,19 +140,23 @@ def eth_evm_bls12381_g2msm(inputs: bytes) -> bytes:
     if len(inputs) == 0 or len(inputs) % 288 != 0:
         raise EvmError(CttEVMStatus.cttEVM_InvalidInputSize)
     recs = [inputs[i:i + 288] for i in range(0, len(inputs), 288)]
-    rows, on_curve = [], []
+    rows, parse = [], []
     for rec in recs:
-        x = (_fp(rec[0:64]), _fp(rec[64:128]))
-        y = (_fp(rec[128:192]), _fp(rec[192:256]))
+        co = [_fp_or_none(rec[i:i + 64]) for i in (0, 64, 128, 192)]
+        if any(v is None for v in co):
+            parse.append(_TOO_LARGE)
+            rows.append(bytes(192))
+            continue
+        x, y = (co[0], co[1]), (co[2], co[3])
         ok = True
         if not (x == (0, 0) and y == (0, 0)):
             x3 = _fp2_mul(_fp2_mul(x, x), x)
             y2 = _fp2_mul(y, y)
             ok = ((y2[0] - x3[0] - 4) % _P, (y2[1] - x3[1] - 4) % _P) == (0, 0)   # b' = 4(1 + i)
-        on_curve.append(ok)
-        rows.append(_mont(x[0]) + _mont(x[1]) + _mont(y[0]) + _mont(y[1]))
+        parse.append(_OK if ok else _OFF_CURVE)
+        rows.append(_mont(x[0]) + _mont(x[1]) + _mont(y[0]) + _mont(y[1]) if ok else bytes(192))
     pts = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), 192)
-    _validate("bls12_381_g2", pts, on_curve)
+    _validate("bls12_381_g2", pts, parse)
     res = _jac_to_affine(True, multiScalarMul_vartime("bls12_381_g2", _scalars(recs, 256), pts, coord="jac"))
     if res is None:
         return bytes(256)

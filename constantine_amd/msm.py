@@ -337,8 +337,15 @@ class CttEngine:
     def get_coeffs_descriptor(self, coeffs):
         return np.ascontiguousarray(coeffs, dtype=np.uint8)
 
-    def get_base_descriptor(self, bases, table=True):
-        # with the window table (CachedBases): bits/c + 1 multiples of every base resident in HBM, one bucket set per MSM
+    TABLE_BYTES_AUTO = 2 << 30
+
+    def get_base_descriptor(self, bases, table=None):
+        # table=True: the window table (CachedBases) -- bits/c + 1 multiples of every base resident in HBM (13-17x the plain
+        # records) and c*(bits/c) doublings per base to build, one bucket set per MSM afterwards.  Automatic (None): only while
+        # the table stays below TABLE_BYTES_AUTO; the library itself falls back to plain records when a table does not fit.
+        if table is None:
+            n = len(bases)
+            table = n * 17 * 128 <= self.TABLE_BYTES_AUTO
         return CachedBases(self.CURVE, bases, table=table)
 
     def msm_with_cached_scalars(self, coeffs_desc, bases):

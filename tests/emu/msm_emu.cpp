@@ -13,7 +13,12 @@
 using namespace ctt;
 
 struct EmuBackend {
-  void* alloc(size_t b) { return malloc(b); }
+  // EMU_ALLOC_LIMIT (bytes): larger requests fail the way hipMalloc does on a full device (tests of the fallbacks)
+  void* alloc(size_t b) {
+    const char* lim = getenv("EMU_ALLOC_LIMIT");
+    if (lim && b > (size_t)strtoull(lim, nullptr, 10)) throw OutOfDeviceMemory{b};
+    return malloc(b);
+  }
   void free(void* p) { ::free(p); }
   void memset0(void* p, size_t b) { memset(p, 0, b); }
   void d2d_async(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
@@ -245,6 +250,7 @@ struct EmuCurve {
     emu_env_options(eng.opt);
     int cu = 0;
     void* tab = eng.prepare_table((const Affine<F>*)points, (uint32_t)ntab, c, &cu);
+    if (!tab && ntab) tab = eng.prepare_bases((const Affine<F>*)points, (uint32_t)ntab);   // (what bases_create does: plain records)
     int s0 = eng.submit((const uint32_t*)coefs, coef_is_fr != 0, nullptr, (uint32_t)n, tab, cu, (uint32_t)ntab);
     auto res = eng.finish(s0);
     if (tab) bk.free(tab);
@@ -267,6 +273,7 @@ struct EmuCurve {
       case 3: o = F::sub(x, y); break;
       case 4: o = F::neg(x); break;
       case 5: o = F::inv(x); break;
+      case 6: if constexpr (!IsFp2<F>::value) o = F::inv_fermat(x); else o = F::inv(x); break;
     }
   }
   // device-field probe: inputs in the reference representation, output raw FD limbs (uint32[NL]); returns NL

@@ -45,10 +45,15 @@ def test_field_ops_vs_python(name):
         assert F.from_mont_bytes(bytes(emu.field_op(name, 2, enc(a), enc(b)))) == F.add(a, b)
         assert F.from_mont_bytes(bytes(emu.field_op(name, 3, enc(a), enc(b)))) == F.sub(a, b)
         assert F.from_mont_bytes(bytes(emu.field_op(name, 4, enc(a)))) == F.neg(a)
-    for _ in range(4):
-        a = rnd()
-        if not F.is_zero(a):
-            assert F.from_mont_bytes(bytes(emu.field_op(name, 5, enc(a)))) == F.inv(a)
+    # inversion by division steps (modinv.h) against Python, and against a^(p-2) (op 6, rounds 1-2's inversion); inv(0) = 0
+    specials = [1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << (p.bit_length() - 1), base.R % p, pow(base.R, -1, p)]
+    for v in specials + [rng.randrange(1, p) for _ in range(60)]:
+        a = v if F.degree == 1 else (v, rng.choice([0, 1, p - 1, rng.randrange(p)]))
+        got = F.from_mont_bytes(bytes(emu.field_op(name, 5, enc(a))))
+        assert got == F.inv(a), (name, a)
+        assert F.from_mont_bytes(bytes(emu.field_op(name, 6, enc(a)))) == got
+    zero = F.from_int(0)
+    assert F.is_zero(F.from_mont_bytes(bytes(emu.field_op(name, 5, enc(zero)))))
 
 
 @pytest.mark.parametrize("name", ALL)
@@ -333,6 +338,27 @@ def test_tickets_finished_out_of_order():
     assert refused == 0
     for i in range(3):
         assert bytes(out[i]) == bytes(expect), i
+
+
+def test_window_table_falls_back_when_memory_or_window_bits_do_not_fit(monkeypatch):
+    """a window table that does not fit the device comes back as "no table" (plain records, same result) instead of
+    an abort, and a caller's window_bits outside 2..22 is replaced by the automatic choice."""
+    name = "pallas"
+    curve = po.CURVES[name]
+    n = 64
+    pts = cref.gen_points(name, 921, n)
+    sc = cref.synth_scalars(922, n, 255)
+    expect, _ = cref.msm(name, sc, pts)
+    for c in (1, 23, 31, 40):
+        out, cu = emu.msm_table(name, sc, pts, c=c)
+        assert 4 <= cu <= 22 and bytes(out) == bytes(expect), (c, cu)
+    n = 2000
+    pts = cref.gen_points(name, 923, n)
+    sc = cref.synth_scalars(924, n, 255)
+    expect, _ = cref.msm(name, sc, pts)
+    monkeypatch.setenv("EMU_ALLOC_LIMIT", str(2 << 20))      # the table (>= 12 levels of n records: > 3 MiB) does not fit, the rest does
+    out, cu = emu.msm_table(name, sc, pts, c=0)
+    assert cu == 0 and bytes(out) == bytes(expect)
 
 
 def test_plan_fits_the_gpu_for_any_size():

@@ -58,7 +58,11 @@ def test_status_is_that_of_the_first_offending_point():
     off_curve = (1).to_bytes(64, "big") + (1).to_bytes(64, "big")
     good = bytes.fromhex(DOC["g1"][0][1])[:128]
     k = (5).to_bytes(32, "big")
+    too_large = b"\x00" * 16 + b"\xff" * 48 + (1).to_bytes(64, "big")     # x >= p: parsed in pair order like the rest
     for pts, want in (((off_subgroup, off_curve), "cttEVM_PointNotInSubgroup"),
+                      ((good, off_curve, too_large), "cttEVM_PointNotOnCurve"),
+                      ((good, off_subgroup, too_large), "cttEVM_PointNotInSubgroup"),
+                      ((good, too_large, off_curve, off_subgroup), "cttEVM_IntLargerThanModulus"),
                       ((good, off_curve, off_subgroup), "cttEVM_PointNotOnCurve"),
                       ((good, good, off_subgroup, off_curve), "cttEVM_PointNotInSubgroup"),
                       ((off_curve, off_subgroup), "cttEVM_PointNotOnCurve")):
