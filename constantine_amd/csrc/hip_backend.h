@@ -85,6 +85,16 @@ __global__ void __launch_bounds__(EC_BLOCK) k_merge_step(MergeArgs<F> a, uint32_
   merge_step_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, d);
 }
 template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_final(MergeArgs<F> a) {
+  if (merge_chain_bound<F>(a) <= 1) return;   // the tail merge wrote the buckets
+  merge_final_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_pyr(PyrArgs<F> a, uint32_t ntasks) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ntasks) pyr_body<F>(a, blockIdx.y, t);
+}
+template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
   bucket_sum_body<F>(sets, nsets, set_elems, blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -233,72 +243,24 @@ __device__ __forceinline__ void xyzz_add_quad_reg(XYZZ<F>& acc, const XYZZ<F>& q
   acc.zz = quad_bcast<2>(T3);
   acc.zzz = quad_bcast<3>(T4);
 }
-// --- bucket reduction in two launches (msm_bodies.h ReduceArgs) ---------------------------------------------------------
-// One pass = a list of independent tasks (*d1 = *s1 + *s2).  The lanes of the workgroup stride over it, one lane per task
-// while the pass is wide, four lanes per task (xyzz_add_quad: 4 products deep instead of 14) once that takes fewer than
-// quad_ratio times the rounds: a round of one-lane additions costs ~10-17 us, a round of four-lane additions ~4.5 us.
-static constexpr int RED_BLOCK = 256;
-template <class F, class Decode>
-__device__ __forceinline__ void reduce_pass(uint32_t ntasks, uint32_t quad_ratio, Decode&& decode) {
-  const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  const uint32_t rounds1 = (ntasks + nt - 1) / nt, rounds4 = (4u * ntasks + nt - 1) / nt;
-  const XYZZ<F>* s1;
-  const XYZZ<F>* s2;
-  XYZZ<F>* d1;
-  XYZZ<F>* d2;
-  if (rounds4 < quad_ratio * rounds1) {
-    const int role = (int)(tid & 3u);
-    for (uint32_t t = tid >> 2; t < ntasks; t += nt >> 2) {   // t is the same for the four lanes of a quad
-      if (!decode(t, s1, s2, d1, d2)) continue;
-      if (!s2) {
-        if (role == 0) reduce_task_run<F>(s1, s2, d1, d2);
-        continue;
-      }
-      xyzz_add_quad<F>(s1, s2, d1, d2, role);
-    }
-  } else {
-    for (uint32_t t = tid; t < ntasks; t += nt)
-      if (decode(t, s1, s2, d1, d2)) reduce_task_run<F>(s1, s2, d1, d2);
-  }
-}
-// level 1: workgroup (j, w) takes block j of window w through its k pyramid passes; the levels and trees of the block live
-// in its own slice of the scratch arrays (written and re-read by this workgroup only: they stay in the XCD's L2)
-template <class F>
-__global__ void __launch_bounds__(RED_BLOCK) k_reduce_blocks(ReduceArgs<F> a) {
-  const uint32_t j = blockIdx.x, w = blockIdx.y;
-  for (int p = 0; p < a.k; p++) {
-    const PyrArgs<F> v = reduce_block_view<F>(a, w, j, p);
-    reduce_pass<F>(pyr_pass_tasks(a.BLK, a.k + 1, p), a.quad_ratio,
-                   [&](uint32_t t, const XYZZ<F>*& s1, const XYZZ<F>*& s2, XYZZ<F>*& d1, XYZZ<F>*& d2) {
-                     return pyr_decode<F>(v, 0, t, s1, s2, d1, d2);
-                   });
-    __syncthreads();
-  }
-}
-// level 2 + bit Horner: one workgroup per window.  The Horner of group g (bits [g*h, g*h + h) of the bucket index, TOP joins
-// group 0) is walked by quad g with the accumulator resident in registers -- every lane of the quad holds a full copy; a
-// doubling is 3 rounds of independent products, an addition 4:
+// --- bit Horner of a window in groups of h bits: P_{w,g} = sum_{l in group g} 2^(l - g h) O_l (+ TOP in group 0) -----------
+// One quad of lanes per (window, group) walks its chain with the accumulator resident in registers (every lane of the quad
+// holds a full copy): a doubling is 3 rounds of independent products, an addition 4 --
 //   doubling  round 1   V = U^2 (U = 2Y)   XX = X^2         -                -
 //             round 2   Wv = U*V           S = X*V          MM = Mm^2        -              (Mm = 3 XX)
 //             round 3   A = Mm*(S-X3)      Bv = Wv*Y        ZZ3 = V*ZZ       ZZZ3 = Wv*ZZZ  (X3 = MM - 2S, Y3 = A - Bv)
+// a round costs ~1.8 us.  Round 2 ran ONE quad per window over all c - 1 bits (k_window_sums: 15 x 7 + 4 rounds = 200 us for
+// BLS12-381 at c = 16) or left the whole bit Horner to the host; with groups of h = 4 bits the chain is 3 x 7 + 4 rounds (45 us)
+// and the host's Horner over the windows -- W c doublings whatever h is -- takes ngrp - 1 more additions per window.
 template <class F>
-__global__ void __launch_bounds__(RED_BLOCK) k_reduce_finish(ReduceArgs<F> a) {
-  const uint32_t w = blockIdx.x;
-  const int c2 = a.c - a.k;
-  for (int s = 0; s < c2 - 1; s++) {
-    reduce_pass<F>(reduce_finish_tasks(a.nb, c2, a.k, s), a.quad_ratio,
-                   [&](uint32_t t, const XYZZ<F>*& s1, const XYZZ<F>*& s2, XYZZ<F>*& d1, XYZZ<F>*& d2) {
-                     return reduce_finish_decode<F>(a, w, s, t, s1, s2, d1, d2);
-                   });
-    __syncthreads();
-  }
+__global__ void __launch_bounds__(EC_BLOCK) k_window_groups(const XYZZ<F>* out, XYZZ<F>* wsum, int c, int h, int ngrp) {
   const uint32_t tid = threadIdx.x;
-  if (tid >= 4u * (uint32_t)a.ngrp) return;
+  if (tid >= 4u * (uint32_t)ngrp) return;
   const int role = (int)(tid & 3u), g = (int)(tid >> 2);
-  const XYZZ<F>* o = a.out + (size_t)w * a.c;
-  const int lo = g * a.h;
-  int hi = lo + a.h;
-  if (hi > a.c - 1) hi = a.c - 1;
+  const XYZZ<F>* o = out + (size_t)blockIdx.x * c;
+  const int lo = g * h;
+  int hi = lo + h;
+  if (hi > c - 1) hi = c - 1;
   XYZZ<F> r = XYZZ<F>::inf();
   for (int l = hi - 1; l >= lo; l--) {
     xyzz_dbl_quad_reg<F>(r, role);
@@ -306,11 +268,35 @@ __global__ void __launch_bounds__(RED_BLOCK) k_reduce_finish(ReduceArgs<F> a) {
     xyzz_add_quad_reg<F>(r, y, role);
   }
   if (g == 0) {
-    const XYZZ<F> top = o[a.c - 1];
+    const XYZZ<F> top = o[c - 1];
     xyzz_add_quad_reg<F>(r, top, role);
   }
-  if (role == 0) a.wsum[(size_t)w * a.ngrp + g] = r;
+  if (role == 0) wsum[(size_t)blockIdx.x * ngrp + g] = r;
 }
+
+// a narrow pass of the bucket reduction: four lanes per addition (xyzz_add_quad)
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_pyr_quad(PyrArgs<F> a, uint32_t ntasks) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = lane >> 2;
+  const int role = (int)(lane & 3u);
+  const XYZZ<F>* s1;
+  const XYZZ<F>* s2;
+  XYZZ<F>* d1;
+  XYZZ<F>* d2;
+  const bool live = t < ntasks && pyr_decode<F>(a, blockIdx.y, t, s1, s2, d1, d2);
+  if (!live) return;  // whole quads leave together (t is the same for the four lanes)
+  if (!s2) {
+    if (role == 0) {
+      const XYZZ<F> x = *s1;
+      *d1 = x;
+      if (d2) *d2 = x;
+    }
+    return;
+  }
+  xyzz_add_quad<F>(s1, s2, d1, d2, role);
+}
+static constexpr int RED_BLOCK = 256;
 // end of the head merge: one workgroup per window (msm_bodies.h merge_finish_body)
 template <class F>
 __global__ void __launch_bounds__(RED_BLOCK) k_merge_finish(MergeArgs<F> a, uint32_t first_d) {
@@ -379,12 +365,15 @@ struct HipBackend {
   hipEvent_t ev_tail_fork = nullptr, ev_tail_done = nullptr;
   bool on_aux = false, tail_pending = false;
   hipStream_t cur() const { return on_aux ? aux : stream; }
+  bool no_tail = false;   // experiment knob ($CTT_HIP_MSM_NO_TAIL): everything on the main stream
   void tail_begin() {
+    if (no_tail) return;
     HIP_CHECK(hipEventRecord(ev_tail_fork, stream));
     HIP_CHECK(hipStreamWaitEvent(aux, ev_tail_fork, 0));
     on_aux = true;
   }
   void tail_end() {
+    if (no_tail) return;
     HIP_CHECK(hipEventRecord(ev_tail_done, aux));
     on_aux = false;
     tail_pending = true;
@@ -394,6 +383,16 @@ struct HipBackend {
     if (!tail_pending) return;
     HIP_CHECK(hipStreamWaitEvent(stream, ev_tail_done, 0));
     tail_pending = false;
+  }
+  static uint32_t quad_threshold() {
+    static const uint32_t v = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 24576u;
+    return v;  // measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768
+  }
+  static bool pyr_is_narrow(uint32_t ntasks, uint32_t W) { return (uint64_t)ntasks * W <= quad_threshold(); }
+  // passes with at most this many additions (all windows) go to the tail stream
+  static bool pyr_goes_to_tail(uint32_t ntasks, uint32_t W) {
+    static const uint32_t v = getenv("CTT_HIP_MSM_TAIL") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_TAIL")) : 131072u;  // about what fits under the next MSM's conversion + sort (measured 2^20: 3.34 ms at 24576, 3.30 at 131072; above that the tail queues behind the next accumulation)
+    return (uint64_t)ntasks * W <= v;
   }
   int num_cu = 256;
   // stage events per in-flight slot; a host-pointer MSM runs the first stages once per upload slice (MsmEngine::submit_host):
@@ -537,9 +536,12 @@ struct HipBackend {
     hipLaunchKernelGGL(k_merge_step<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, d);
     HIP_CHECK(hipGetLastError());
   }
+  // the steps beyond those the plan enqueued (unusual inputs only: returns at once otherwise), then the chain heads -> buckets
   template <class F>
   void launch_merge_finish(const MergeArgs<F>& a, uint32_t W, uint32_t first_d) {
     hipLaunchKernelGGL(k_merge_finish<F>, dim3(W), dim3(RED_BLOCK), 0, stream, a, first_d);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_merge_final<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
@@ -547,29 +549,21 @@ struct HipBackend {
     hipLaunchKernelGGL(k_bucket_sum<F>, grid1(set_elems, EC_BLOCK), dim3(EC_BLOCK), 0, stream, sets, nsets, set_elems);
     HIP_CHECK(hipGetLastError());
   }
-  // wave slots of the chip for the reduction kernels (their additions need about as many registers as the accumulation's)
   template <class F>
-  uint32_t reduce_wave_slots() {
-    static uint32_t v = 0;
-    if (!v) {
-      int nb = 0;
-      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_reduce_blocks<F>, 64, 0));
-      v = (uint32_t)(nb < 1 ? 1 : nb) * (uint32_t)num_cu;
-    }
-    return v;
-  }
-  template <class F>
-  void launch_reduce_blocks(const ReduceArgs<F>& a, uint32_t W) {
-    // as many lanes per block as keeps every workgroup resident at once: more lanes = fewer rounds per pass
-    const uint64_t wgs = (uint64_t)a.nb * W, slots = reduce_wave_slots<F>();
-    static const int force = getenv("CTT_HIP_MSM_RED_NT") ? atoi(getenv("CTT_HIP_MSM_RED_NT")) : 0;
-    int nt = force > 0 ? force : wgs * 4u <= slots ? 256 : wgs * 2u <= slots ? 128 : 64;
-    hipLaunchKernelGGL(k_reduce_blocks<F>, dim3(a.nb, W), dim3(nt), 0, cur(), a);
+  void launch_window_groups(const XYZZ<F>* out, XYZZ<F>* wsum, uint32_t W, int c, int h, int ngrp) {
+    const int nt = ((4 * ngrp + EC_BLOCK - 1) / EC_BLOCK) * EC_BLOCK;
+    hipLaunchKernelGGL(k_window_groups<F>, dim3(W), dim3(nt), 0, cur(), out, wsum, c, h, ngrp);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
-  void launch_reduce_finish(const ReduceArgs<F>& a, uint32_t W) {
-    hipLaunchKernelGGL(k_reduce_finish<F>, dim3(W), dim3(RED_BLOCK), 0, cur(), a);
+  void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
+    // few tasks left: four lanes per addition (the chip is mostly idle, the addition is 3.5x shallower)
+    if (pyr_is_narrow(ntasks, W)) {
+      hipLaunchKernelGGL(k_pyr_quad<F>, grid2(ntasks * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, ntasks);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+    hipLaunchKernelGGL(k_pyr<F>, grid2(ntasks, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, ntasks);
     HIP_CHECK(hipGetLastError());
   }
 };

@@ -413,20 +413,17 @@ CTT_HD void merge_final_body(const MergeArgs<F>& a, uint32_t w, uint32_t g) {
   a.buckets[(uint64_t)w * a.B + b] = a.heads[slot];
 }
 
-// End of the merge, one workgroup per window (the GPU kernel strides its lanes over g and puts a workgroup barrier where
-// `sync` is called): nothing to do when the tail merge wrote the buckets (chains of length one); otherwise the tree steps
-// d = first_d, 2 first_d, ... that the wide step kernels launched before it did not cover -- the host enqueues as many wide
-// steps as an ordinary digit distribution needs WITHOUT knowing the largest bucket, an adversarial input (all scalars equal:
-// chains of G heads) finishes its tree here -- and then the chain heads become the buckets.
+// The tree steps d = first_d, 2 first_d, ... that the wide step kernels launched before it did not cover, one workgroup per
+// window (the GPU kernel strides its lanes over g and puts a workgroup barrier where `sync` is called).  The host enqueues as
+// many wide steps as an ordinary digit distribution needs WITHOUT knowing the largest bucket (MsmPlan::merge_steps); for
+// such inputs this returns at once.  An adversarial input (all scalars equal: chains of G heads) finishes its tree here.
 template <class F, class Sync>
 CTT_HD void merge_finish_body(const MergeArgs<F>& a, uint32_t w, uint32_t first_d, uint32_t lane, uint32_t nlanes, Sync&& sync) {
   const uint32_t chain = merge_chain_bound<F>(a);
-  if (chain <= 1) return;
   for (uint32_t d = first_d; d < chain; d <<= 1) {
     for (uint32_t g = lane; g < a.G; g += nlanes) merge_step_body<F>(a, w, g, d);
     sync();
   }
-  for (uint32_t g = lane; g < a.G; g += nlanes) merge_final_body<F>(a, w, g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,103 +561,6 @@ CTT_HD void pyr_body(const PyrArgs<F>& a, uint32_t w, uint32_t t) {
   if (d2) *d2 = x;
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same reduction in TWO launches (round 3).  Pass p of the pyramid only combines elements of one aligned block of
-// 2^(p+1) buckets, so an aligned block of BLK = 2^k buckets can be taken through its first k passes by ONE workgroup
-// (workgroup barriers between the passes instead of kernel boundaries):
-//
-//   level 1 (reduce_block_*)   per block j of window w: the block-local O_0 .. O_{k-1} (sums of the block's buckets whose
-//                              LOCAL index has bit l set) and the block total T_j, written as columns cols[w][l][j]
-//   level 2 (reduce_finish_*)  per window, one workgroup: O_l = sum_j cols[l][j] for l < k (k plain trees over the nb = B/BLK
-//                              blocks), and the pyramid over the block totals T_j gives O_k .. O_{c-2} and TOP -- bit l >= k
-//                              of a bucket index is bit l-k of its block index.  Both have log2(nb) passes.
-//                              Then the Horner over the bits, split into groups of h bits (window_group_sum_body): the
-//                              device returns ngrp = ceil((c-1)/h) partial sums per window and the host's Horner over the
-//                              windows (which has to walk W*c doublings anyway) joins them (combine_groups, msm_pipeline.h).
-// k = 0 (few buckets): level 2 alone, its pyramid runs over the buckets themselves.
-// ---------------------------------------------------------------------------------------------
-template <class F>
-struct ReduceArgs {
-  const XYZZ<F>* buckets;  // [W][B]
-  XYZZ<F>* pyr;            // [W][B]        scratch: pyramid levels of the blocks
-  XYZZ<F>* q;              // [W][B/2]      scratch: odd-element trees of the blocks
-  XYZZ<F>* cols;           // [W][k+1][nb]  block results: O_0 .. O_{k-1} of every block, then the block totals
-  XYZZ<F>* pyr2;           // [W][nb]       scratch of level 2 (pyramid over the block totals)
-  XYZZ<F>* q2;             // [W][nb/2+1]
-  XYZZ<F>* out;            // [W][c]        O_0 .. O_{c-2}, TOP  (nb == 1: level 1 writes it directly, cols == out)
-  XYZZ<F>* wsum;           // [W][ngrp]     partial Horner sums of the window
-  uint32_t B, BLK, nb;     // buckets per window, per block, blocks per window (BLK * nb == B; k == 0: BLK = 1)
-  int c, k, h, ngrp;       // window bits; log2(BLK); bits per Horner group; groups per window
-  uint32_t quad_ratio;     // GPU: a pass runs with four lanes per addition while that takes fewer than quad_ratio x the rounds
-};
-
-// level 1: the pyramid passes of block j of window w seen as a pyramid of its own (pyr_decode with w = 0)
-template <class F>
-CTT_HD PyrArgs<F> reduce_block_view(const ReduceArgs<F>& a, uint32_t w, uint32_t j, int p) {
-  PyrArgs<F> v;
-  const uint64_t off = (uint64_t)w * a.B + (uint64_t)j * a.BLK;
-  v.buckets = a.buckets + off;
-  v.pyr = a.pyr + off;
-  v.q = a.q + off / 2;
-  v.out = a.cols + (uint64_t)w * (uint64_t)(a.k + 1) * a.nb + j;
-  v.out_stride = a.nb;
-  v.B = a.BLK;
-  v.c = a.k + 1;
-  v.p = p;
-  return v;
-}
-// level 2: the pyramid over the block totals of window w (the buckets themselves when k == 0)
-template <class F>
-CTT_HD PyrArgs<F> reduce_finish_view(const ReduceArgs<F>& a, uint32_t w, int s) {
-  PyrArgs<F> v;
-  v.buckets = a.k == 0 ? a.buckets + (uint64_t)w * a.B : a.cols + ((uint64_t)w * (uint64_t)(a.k + 1) + (uint64_t)a.k) * a.nb;
-  v.pyr = a.pyr2 + (uint64_t)w * a.nb;
-  v.q = a.q2 + (uint64_t)w * (a.nb / 2 + 1);
-  v.out = a.out + (uint64_t)w * a.c + a.k;
-  v.out_stride = 1;
-  v.B = a.nb;
-  v.c = a.c - a.k;
-  v.p = s;
-  return v;
-}
-// tasks of level-2 pass s: the pyramid's, then k column trees with (nb >> s) / 2 additions each
-CTT_HD uint32_t reduce_finish_tasks(uint32_t nb, int c2, int k, int s) {
-  return pyr_pass_tasks(nb, c2, s) + (uint32_t)k * ((nb >> s) / 2);
-}
-template <class F>
-CTT_HD bool reduce_finish_decode(const ReduceArgs<F>& a, uint32_t w, int s, uint32_t t, const XYZZ<F>*& s1, const XYZZ<F>*& s2,
-                                 XYZZ<F>*& d1, XYZZ<F>*& d2) {
-  const uint32_t npyr = pyr_pass_tasks(a.nb, a.c - a.k, s);
-  if (t < npyr) {
-    const PyrArgs<F> v = reduce_finish_view<F>(a, w, s);
-    return pyr_decode<F>(v, 0, t, s1, s2, d1, d2);
-  }
-  const uint32_t half = (a.nb >> s) / 2;
-  const uint32_t u = t - npyr;
-  s1 = nullptr;
-  s2 = nullptr;
-  d1 = nullptr;
-  d2 = nullptr;
-  if (half == 0 || u >= (uint32_t)a.k * half) return false;
-  const uint32_t l = u / half, i = u - l * half;
-  XYZZ<F>* col = a.cols + ((uint64_t)w * (uint64_t)(a.k + 1) + l) * a.nb;
-  s1 = col + i;
-  s2 = col + i + half;
-  d1 = col + i;
-  if (half == 1) d2 = a.out + (uint64_t)w * a.c + l;
-  return true;
-}
-// one task: *d1 (and *d2) = *s1 + *s2, or a copy (the GPU's four-lane form is in hip_backend.h)
-template <class F>
-CTT_HD void reduce_task_run(const XYZZ<F>* s1, const XYZZ<F>* s2, XYZZ<F>* d1, XYZZ<F>* d2) {
-  XYZZ<F> x = *s1;
-  if (s2) {
-    XYZZ<F> y = *s2;
-    x = xyzz_add_inl<F>(x, y);
-  }
-  *d1 = x;
-  if (d2) *d2 = x;
-}
 // groups of the bit Horner: group g covers bits [g*h, min((g+1)*h, c-1)) of the bucket index
 CTT_HD int horner_groups(int c, int h) { return c > 1 ? (c - 1 + h - 1) / h : 1; }
 

@@ -35,9 +35,6 @@ struct MsmPlan {
   uint32_t merged;     // 1 = window-table form
   uint32_t nent;       // entries per bucket set: n, or Wd*n
   uint32_t id_stride;  // table rows per window (the cached bases' length; a call may use a prefix)
-  // bucket reduction in two launches (msm_bodies.h ReduceArgs): blocks of 2^rk buckets, rnb blocks per window
-  int rk;
-  uint32_t rnb;
   int h, ngrp;         // bit Horner: bits per group, groups per window (the device returns W*ngrp partial sums)
   int merge_steps;     // wide head-merge tree steps enqueued without knowing the largest bucket (plan_merge_steps)
 };
@@ -49,9 +46,7 @@ struct MsmOptions {
   uint32_t lanes = 196608;  // resident lanes of the accumulate kernel (set by the backend)
   int host_window_sums = 0;  // legacy spelling of horner_bits: 1 = 1 bit per group (the whole bit Horner on the host),
                              // 2 = one group per window (the whole bit Horner on the device), 0 = horner_bits decides
-  int horner_bits = 0;       // bits per group of the bit Horner the device runs (0 = choose: 4); see plan_reduce
-  int reduce_block = 0;      // log2 of the buckets one workgroup of the first reduction launch takes (0 = choose)
-  int quad_ratio = 0;        // reduction passes run four lanes per addition while that needs < quad_ratio x the rounds (0 = 3)
+  int horner_bits = 0;       // bits per group of the bit Horner the device runs (0 = choose: 4); see plan_horner
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -116,21 +111,9 @@ static inline int choose_window_bits(uint32_t n, int bits, uint32_t lanes) {
   return bc;
 }
 
-// Shape of the bucket reduction (msm_bodies.h ReduceArgs).  Few buckets (B <= 512): the one-workgroup-per-window launch
-// does everything.  Otherwise a first launch takes blocks of 2^rk >= 256 buckets each, at most 256 blocks per window, so that
-// the per-window workgroup of the second launch is left with <= 256 block totals and rk column trees over <= 256 elements.
-static inline void plan_reduce(MsmPlan& p, const MsmOptions& o) {
-  int lb = 0;
-  while ((1u << lb) < p.B) lb++;   // B = 2^lb
-  int rk = 0;
-  if (p.B > 512u) {
-    rk = o.reduce_block > 0 ? o.reduce_block : 8;
-    if (rk < 1) rk = 1;
-    while (lb - rk > 8) rk++;      // nb <= 256
-    if (rk > lb) rk = lb;
-  }
-  p.rk = rk;
-  p.rnb = p.B >> rk;
+// Groups of the bit Horner (hip_backend.h k_window_groups, window_group_sum_body): h bits per group, the device returns
+// ngrp = ceil((c-1)/h) partial sums per window.
+static inline void plan_horner(MsmPlan& p, const MsmOptions& o) {
   int h = o.host_window_sums == 1 ? 1 : o.host_window_sums == 2 ? p.c : o.horner_bits > 0 ? o.horner_bits : 4;
   if (h > p.c) h = p.c;
   p.h = h;
@@ -213,7 +196,7 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   p.merged = 0;
   p.nent = n;
   p.id_stride = 0;
-  plan_reduce(p, o);
+  plan_horner(p, o);
   p.merge_steps = plan_merge_steps(p, bits);
   return p;
 }
@@ -300,7 +283,7 @@ static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab
   if (K < 4) K = 4;
   p.K = K;
   p.G = (p.nent + K - 1) / K;
-  plan_reduce(p, o);
+  plan_horner(p, o);
   p.merge_steps = plan_merge_steps(p, bits);
   return p;
 }
@@ -352,11 +335,11 @@ struct MsmEngine {
 
   // grow-only workspace
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf part, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], rC, rS[2], scal, maxcount, cpoints, totals, gbase;
+  Buf part, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcount, cpoints, totals, gbase;
 
   explicit MsmEngine(BK& b) : bk(b) {}
   ~MsmEngine() {
-    Buf* all[] = {&part, &gbase, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &rC, &rS[0], &rS[1], &scal, &maxcount, &cpoints, &totals};
+    Buf* all[] = {&part, &gbase, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount, &cpoints, &totals};
     for (Buf* b : all) if (b->p) bk.free(b->p);
     for (Slot& sl : slots) if (sl.hraw) bk.free_host(sl.hraw);
   }
@@ -568,46 +551,52 @@ struct MsmEngine {
     bk.stage_end(sl, ST_MERGE);
   }
 
-  // Stage 3: bucket reduction (two launches), bit Horner in groups, and the copy of the W*ngrp partial sums to the slot's
-  // pinned buffer.
+  // Stage 3: bucket reduction (c-1 pyramid passes, one launch each: every wave of a launch runs the same straight-line
+  // addition at the same time, which is what keeps its 64 KiB of code flowing through the instruction caches), the bit Horner
+  // in groups, and the copy of the W*ngrp partial sums to the slot's pinned buffer.
+  // Round 3 measured the alternative the round-2 review asked for -- an aligned block of 256..1024 buckets taken through its
+  // pyramid levels by ONE workgroup, workgroup barriers instead of launches, and one workgroup per window for the rest: two
+  // launches instead of c-1.  Same box, BLS12-381 G1 2^20: 332 + 217 us against 315 + 75 (+ 45 us of Horner in both); 2^16:
+  // 128 + 91 against 67 + 88.  A narrow pass is ~10 us of which ~7 us is the latency of one four-lane addition, which a fused
+  // kernel pays as well, and a launch spreads every level over the whole chip where a workgroup has 256 lanes; the waves of a
+  // fused kernel also drift apart (different passes, different task kinds) and each then streams the addition's code through
+  // the instruction cache on its own.  profiles/reduce_fused_vs_passes_r03.txt; the code is in the history (a64cd06).
   void reduce_buckets(int sl, const MsmPlan& p, XYZZ<FD>* d_buckets) {
     Slot& S = slots[sl];
-    const size_t W = p.W, B = p.B, nb = p.rnb;
+    const uint32_t W = p.W, B = p.B;
     bk.tail_wait();   // (a no-op unless accumulate_pairs left the previous tail running: small MSMs)
     bk.stage_begin(sl, ST_REDUCE);
-    ReduceArgs<FD> ra;
-    ra.buckets = d_buckets;
-    ra.pyr = p.rk ? (XYZZ<FD>*)need(rA[0], W * B * sizeof(XYZZ<FD>)) : nullptr;
-    ra.q = p.rk ? (XYZZ<FD>*)need(rA[1], W * (B / 2 + 1) * sizeof(XYZZ<FD>)) : nullptr;
-    ra.out = (XYZZ<FD>*)need(rP[0], W * p.c * sizeof(XYZZ<FD>));
-    ra.cols = (p.rk && nb > 1) ? (XYZZ<FD>*)need(rC, W * (size_t)(p.rk + 1) * nb * sizeof(XYZZ<FD>)) : ra.out;
-    ra.pyr2 = (XYZZ<FD>*)need(rS[0], W * nb * sizeof(XYZZ<FD>));
-    ra.q2 = (XYZZ<FD>*)need(rS[1], W * (nb / 2 + 1) * sizeof(XYZZ<FD>));
-    ra.wsum = (XYZZ<FD>*)need(rP[1], W * (size_t)p.ngrp * sizeof(XYZZ<FD>));
-    ra.B = p.B;
-    ra.BLK = 1u << p.rk;
-    ra.nb = p.rnb;
-    ra.c = p.c;
-    ra.k = p.rk;
-    ra.h = p.h;
-    ra.ngrp = p.ngrp;
-    ra.quad_ratio = opt.quad_ratio > 0 ? (uint32_t)opt.quad_ratio : 3u;
-    // first launch: the blocks (throughput-bound, stays on the main stream)
-    if (p.rk) bk.template launch_reduce_blocks<FD>(ra, p.W);
-    // second launch: one workgroup per window -- latency-bound, as is the result copy: they move to the backend's tail
-    // stream and the next MSM's conversion and sort run underneath them (the tail_wait() before the accumulation also
-    // orders the previous tail before this MSM's first write to the reduction buffers)
-    bk.tail_begin();
-    bk.template launch_reduce_finish<FD>(ra, p.W);
+    XYZZ<FD>* d_pyr = (XYZZ<FD>*)need(rA[0], (size_t)W * B * sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_q = (XYZZ<FD>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_out = (XYZZ<FD>*)need(rP[0], (size_t)W * p.c * sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_wsum = (XYZZ<FD>*)need(rP[1], (size_t)W * p.ngrp * sizeof(XYZZ<FD>));
+    // The narrow passes at the end, the bit Horner and the result copy move to the backend's tail stream: they are
+    // latency-bound and the next MSM's conversion and sort fit underneath them (the tail_wait() before the accumulation also
+    // orders the previous tail before this MSM's first write to the pyramid buffers).
+    bool forked = false;
+    for (int pass = 0; pass <= p.c - 2; pass++) {
+      PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass, 1u};
+      const uint32_t ntasks = pyr_pass_tasks(B, p.c, pass);
+      if (!forked && pass > 0 && bk.pyr_goes_to_tail(ntasks, W)) {
+        bk.tail_begin();
+        forked = true;
+      }
+      bk.template launch_pyr<FD>(pa, W, ntasks);
+    }
+    if (!forked) {
+      bk.tail_begin();
+      forked = true;
+    }
+    bk.template launch_window_groups<FD>(d_out, d_wsum, W, p.c, p.h, p.ngrp);
     bk.stage_end(sl, ST_REDUCE);
 
-    const size_t bytes = W * (size_t)p.ngrp * sizeof(XYZZ<FD>);
+    const size_t bytes = (size_t)W * p.ngrp * sizeof(XYZZ<FD>);
     if (bytes > S.hcap) {
       if (S.hraw) bk.free_host(S.hraw);
       S.hraw = bk.alloc_host(bytes);
       S.hcap = bytes;
     }
-    bk.d2h_async(sl, S.hraw, ra.wsum, bytes);
+    bk.d2h_async(sl, S.hraw, d_wsum, bytes);
     bk.stage_end(sl, ST_TOTAL);
     bk.tail_end();
   }

@@ -22,21 +22,51 @@ def shard_bounds(n, world_size, rank):
     return start, length
 
 
+class ShardExchange:
+    """The exchange of the partial results, split in two so that it stays off a pipeline's critical path: start() hands this
+    rank's affine partial to an asynchronous all_gather (RCCL's own stream for "nccl"; two buffer sets, so one exchange may be
+    in flight while the next MSM runs), finish() waits for it and sums the world_size partials on the host.  A caller that
+    keeps MSMs in flight finishes exchange i after it has started exchange i+1 (bench.py); msm_sharded() below is the
+    blocking form."""
+
+    def __init__(self, curve, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.curve = curve
+        self.info = CURVES[curve]
+        self.group = group
+        self.dist = dist
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.slot = 0
+        if self.world > 1:
+            dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+            nb = self.info.aff_bytes
+            self.mine = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.all = [[torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.world)] for _ in range(2)]
+
+    def start(self, part):
+        import torch
+        part = np.ascontiguousarray(part, dtype=np.uint8)
+        assert part.shape == (self.info.aff_bytes,)
+        if self.world == 1:
+            return (None, part)
+        k = self.slot
+        self.slot ^= 1
+        self.mine[k].copy_(torch.from_numpy(part))
+        work = self.dist.all_gather(self.all[k], self.mine[k], group=self.group, async_op=True)
+        return (work, k)
+
+    def finish(self, handle, coord="aff"):
+        work, k = handle
+        if work is None:
+            return ec_sum_affine(self.curve, k[None, :], coord=coord)
+        work.wait()
+        allp = np.stack([g.cpu().numpy() for g in self.all[k]])
+        return ec_sum_affine(self.curve, allp, coord=coord)
+
+
 def msm_sharded(curve, local_msm, group=None, device=None, coord="aff"):
     """local_msm() -> this rank's partial result as affine bytes (uint8[2*coord]).
     Gathers the partials of all ranks and returns the combined point (same on every rank)."""
-    import torch
-    import torch.distributed as dist
-
-    info = CURVES[curve]
-    part = np.ascontiguousarray(local_msm(), dtype=np.uint8)
-    assert part.shape == (info.aff_bytes,)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return ec_sum_affine(curve, part[None, :], coord=coord)
-    world = dist.get_world_size(group)
-    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    mine = torch.from_numpy(part).to(dev)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    allp = np.stack([g.cpu().numpy() for g in gathered])
-    return ec_sum_affine(curve, allp, coord=coord)
+    x = ShardExchange(curve, group=group, device=device)
+    return x.finish(x.start(local_msm()), coord=coord)

@@ -130,37 +130,21 @@ struct EmuBackend {
   }
   template <class F>
   void launch_merge_finish(const MergeArgs<F>& a, uint32_t W, uint32_t first_d) {
-    // one "workgroup" of one lane per window: the lane strides over all g, the barrier is a no-op
+    // one "workgroup" of one lane per window: the lane strides over all g, the barrier is a no-op; then the wide final
     for (uint32_t w = 0; w < W; w++) merge_finish_body<F>(a, w, first_d, 0, 1, []() {});
+    if (merge_chain_bound<F>(a) > 1)
+      for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_final_body<F>(a, w, g);
   }
-  // the two launches of the bucket reduction: passes in order, the tasks of a pass in any order (a pass reads only what
-  // earlier passes wrote, except the in-place halvings q[t] += q[t+n] and col[i] += col[i+half] on disjoint elements)
+  static bool pyr_goes_to_tail(uint32_t, uint32_t) { return false; }
   template <class F>
-  void launch_reduce_blocks(const ReduceArgs<F>& a, uint32_t W) {
+  void launch_window_groups(const XYZZ<F>* out, XYZZ<F>* wsum, uint32_t W, int c, int h, int ngrp) {
     for (uint32_t w = 0; w < W; w++)
-      for (uint32_t j = 0; j < a.nb; j++)
-        for (int p = 0; p < a.k; p++) {
-          const PyrArgs<F> v = reduce_block_view<F>(a, w, j, p);
-          const uint32_t nt = pyr_pass_tasks(a.BLK, a.k + 1, p);
-          for (uint32_t t = 0; t < nt; t++) {
-            const XYZZ<F>* s1; const XYZZ<F>* s2; XYZZ<F>* d1; XYZZ<F>* d2;
-            if (pyr_decode<F>(v, 0, t, s1, s2, d1, d2)) reduce_task_run<F>(s1, s2, d1, d2);
-          }
-        }
+      for (int g = 0; g < ngrp; g++) wsum[(size_t)w * ngrp + g] = window_group_sum_body<F>(out + (size_t)w * c, c, h, g);
   }
   template <class F>
-  void launch_reduce_finish(const ReduceArgs<F>& a, uint32_t W) {
-    const int c2 = a.c - a.k;
-    for (uint32_t w = 0; w < W; w++) {
-      for (int s = 0; s < c2 - 1; s++) {
-        const uint32_t nt = reduce_finish_tasks(a.nb, c2, a.k, s);
-        for (uint32_t t = 0; t < nt; t++) {
-          const XYZZ<F>* s1; const XYZZ<F>* s2; XYZZ<F>* d1; XYZZ<F>* d2;
-          if (reduce_finish_decode<F>(a, w, s, t, s1, s2, d1, d2)) reduce_task_run<F>(s1, s2, d1, d2);
-        }
-      }
-      for (int g = 0; g < a.ngrp; g++) a.wsum[(size_t)w * a.ngrp + g] = window_group_sum_body<F>(a.out + (size_t)w * a.c, a.c, a.h, g);
-    }
+  void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
+    // a pass reads only what earlier passes wrote, except the in-place halving q[t] += q[t+n] (disjoint t)
+    for (uint32_t w = 0; w < W; w++) for (uint32_t t = 0; t < ntasks; t++) pyr_body<F>(a, w, t);
   }
 };
 
@@ -194,7 +178,6 @@ struct EmuOps {
 static void emu_env_options(MsmOptions& o) {
   const char* s;
   if ((s = getenv("EMU_HORNER_BITS"))) o.horner_bits = atoi(s);
-  if ((s = getenv("EMU_REDUCE_BLOCK"))) o.reduce_block = atoi(s);
   if ((s = getenv("EMU_HOST_WINDOW_SUMS"))) o.host_window_sums = atoi(s);
 }
 

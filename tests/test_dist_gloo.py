@@ -38,7 +38,19 @@ def _worker(rank, world, port, name, n, q):
         sc = cref.synth_scalars(78, ln, bits, first=start)
         from tests.emu import emu
         res = parallel.msm_sharded(name, lambda: emu.msm(name, sc, pts, out_kind=0)[0])
-        q.put((rank, bytes(res)))
+        # the pipelined form bench.py uses: exchange i is completed after exchange i+1 has been started (two buffer sets);
+        # step k multiplies by k + 1 through the scalars' low word so that a stale buffer would show
+        x = parallel.ShardExchange(name)
+        outs, prev = [], None
+        for k in range(3):
+            sck = sc.copy()
+            sck[:, 0] = (k * 37 + 1) & 0xFF
+            h = x.start(emu.msm(name, sck, pts, out_kind=0)[0])
+            if prev is not None:
+                outs.append(bytes(x.finish(prev)))
+            prev = h
+        outs.append(bytes(x.finish(prev)))
+        q.put((rank, bytes(res), outs))
     finally:
         dist.destroy_process_group()
 
@@ -52,7 +64,9 @@ def test_sharded_msm_two_ranks(name, n):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, name, n, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = dict(q.get(timeout=300) for _ in range(2))
+    got = [q.get(timeout=300) for _ in range(2)]
+    out = {r: a for r, a, _ in got}
+    piped = {r: b for r, _, b in got}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -61,6 +75,11 @@ def test_sharded_msm_two_ranks(name, n):
     sc = cref.synth_scalars(78, n, bits)
     expect, _ = cref.msm(name, sc, pts)
     assert out[0] == out[1] == bytes(expect)
+    for k in range(3):
+        sck = sc.copy()
+        sck[:, 0] = (k * 37 + 1) & 0xFF
+        expect, _ = cref.msm(name, sck, pts)
+        assert piped[0][k] == piped[1][k] == bytes(expect), k
 
 
 def test_shard_bounds_balanced():

@@ -303,23 +303,21 @@ def test_window_table_for_cached_bases(name):
         assert _aff(curve, out) is None
 
 
-def test_reduction_shapes_and_horner_groups(monkeypatch):
-    """The two-launch bucket reduction (msm_bodies.h ReduceArgs) for every block size -- one block per window, blocks of 2
-    buckets, the automatic 256 -- and the bit Horner cut into groups of 1, 2, 3, 4, 7 bits or a single group (the legacy
-    host_window_sums spellings included): the same element whatever the shape."""
+def test_horner_groups(monkeypatch):
+    """The bit Horner cut into groups of 1, 2, 3, 4, 7 bits or a single group per window (the legacy host_window_sums
+    spellings included): the device returns ngrp partial sums per window, the host joins them -- the same element whatever
+    the group size."""
     name = "bn254_snarks_g1"
     n = 400
     pts = cref.gen_points(name, 901, n)
     sc = cref.synth_scalars(902, n, 254)
     expect, _ = cref.msm(name, sc, pts)
     for c in (2, 4, 9, 10, 11, 12, 14):
-        for rb, hb in ((0, 0), (1, 1), (3, 2), (5, 3), (8, 7), (c - 1, 30), (30, 4)):
-            monkeypatch.setenv("EMU_REDUCE_BLOCK", str(rb))
+        for hb in (0, 1, 2, 3, 7, 30):
             monkeypatch.setenv("EMU_HORNER_BITS", str(hb))
             out, plan = emu.msm(name, sc, pts, c=c, K=8)
-            assert bytes(out) == bytes(expect), (c, rb, hb)
+            assert bytes(out) == bytes(expect), (c, hb)
     monkeypatch.delenv("EMU_HORNER_BITS")
-    monkeypatch.delenv("EMU_REDUCE_BLOCK")
     for hws in (1, 2):
         monkeypatch.setenv("EMU_HOST_WINDOW_SUMS", str(hws))
         out, _ = emu.msm(name, sc, pts, c=11, K=8)

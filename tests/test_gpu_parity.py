@@ -323,11 +323,11 @@ def test_window_sizes_and_lane_spans(dev, torch_cuda):
         dev.set_option("S", 0)
 
 
-def test_reduction_shapes_horner_groups_and_merge_without_host_wait(dev, torch_cuda):
-    """Round 3: the bucket reduction is two launches (blocks of 2^rb buckets, then one workgroup per window with the bit
-    Horner cut into groups of hb bits) and the head merge decides on the device how far its tree goes.  Same element for
-    every block size / group size, for uniform digits and for the adversarial inputs whose head chains are far longer than
-    the steps the plan enqueues (all scalars equal; a quarter of them equal)."""
+def test_horner_groups_and_merge_without_host_wait(dev, torch_cuda):
+    """Round 3: the bit Horner of a window is cut into groups of hb bits (one quad of lanes each, joined by the host) and
+    the head merge decides on the device how far its tree goes.  Same element for every group size, for uniform digits and
+    for the adversarial inputs whose head chains are far longer than the steps the plan enqueues (all scalars equal; a
+    quarter of them equal)."""
     torch = torch_cuda
     name = "bls12_381_g1"
     n = 60000
@@ -341,20 +341,13 @@ def test_reduction_shapes_horner_groups_and_merge_without_host_wait(dev, torch_c
         for label, s in (("uniform", sc), ("all equal", sc_eq), ("quarter equal", sc_q)):
             expect = bytes(cref.msm(name, s, pts, nthreads=NT)[0])
             ds = _to_dev(torch, s)
-            for c, rb, hb, K in ((0, 0, 0, 0), (13, 4, 1, 0), (13, 12, 3, 8), (16, 0, 2, 0), (16, 10, 15, 0), (9, 0, 4, 4), (11, 1, 8, 0),
-                                 (15, 7, 5, 12)):
+            for c, hb, K in ((0, 0, 0), (13, 1, 0), (13, 3, 8), (16, 2, 0), (16, 15, 0), (9, 4, 4), (11, 8, 0), (15, 5, 12)):
                 dev.set_option("c", c)
                 dev.set_option("K", K)
-                dev.set_option("reduce_block", rb)
                 dev.set_option("horner_bits", hb)
-                assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (label, c, rb, hb, K, dev.last_plan())
-            for qr in (1, 100):   # never / always four lanes per addition in the reduction passes
-                dev.set_option("quad_ratio", qr)
-                dev.set_option("c", 14)
-                assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (label, "quad_ratio", qr)
-            dev.set_option("quad_ratio", 0)
+                assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (label, c, hb, K, dev.last_plan())
     finally:
-        for k in ("c", "K", "reduce_block", "horner_bits", "quad_ratio"):
+        for k in ("c", "K", "horner_bits"):
             dev.set_option(k, 0)
 
 
@@ -643,6 +636,29 @@ def test_engine_stream_is_ordered_after_torch(dev, torch_cuda):
             big.add_(1)          # keep torch's stream busy in front of the copy that makes the real input
         ds.copy_(good)
         assert bytes(dev.msm(name, ds, dp, n)) == expect
+
+
+def test_host_symbols_shard_over_distinct_devices(torch_cuda):
+    """The in-library sharding on a node with more than one GPU: every context on its own device (skipped on the 1-GPU boxes
+    of the pool, where test_host_symbols_shard_over_contexts runs the same path with the contexts sharing device 0)."""
+    torch = torch_cuda
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("needs at least two GPUs")
+    from constantine_amd import multiScalarMul_vartime_parallel, set_devices, set_shard_min
+    name = "bls12_381_g1"
+    n = 100003
+    pts = cref.gen_points(name, 61, n, nthreads=NT)
+    sc = cref.synth_scalars(62, n, 255)
+    expect = _aff(po.CURVES[name], cref.msm(name, sc, pts, nthreads=NT)[0])
+    try:
+        set_shard_min(1000)
+        for g in sorted({2, min(4, ndev), ndev}):
+            set_devices(list(range(g)))
+            assert _decode(po.CURVES[name], "jac", multiScalarMul_vartime_parallel(None, name, sc, pts, coord="jac")) == expect, g
+    finally:
+        set_devices([])
+        set_shard_min(1 << 15)
 
 
 def test_host_symbols_shard_over_contexts():

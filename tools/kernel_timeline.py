@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
 """Print the per-kernel timeline of the last MSM step from a rocprofv3 rocpd database
-(rocprofv3 --kernel-trace --stats -d DIR -o NAME -- python bench.py ...)  and a per-kernel summary."""
+(rocprofv3 --kernel-trace --stats -d DIR -o NAME -- python bench.py ...)  and a per-kernel summary.
+
+    python tools/kernel_timeline.py <db> [warmup_msms]
+
+warmup_msms: the per-kernel statistics leave out everything dispatched before that many MSMs have started (bench.py's
+warm-up steps: their launches include first-touch allocations and cold caches; round 2's averages contained them)."""
 import collections
 import sqlite3
 import sys
 
 
-def main(path, as_markdown=False):
+def main(path, warm=0):
     con = sqlite3.connect(path)
     cur = con.cursor()
     rows = list(cur.execute(
@@ -22,9 +27,10 @@ def main(path, as_markdown=False):
     for r in last:
         name = r[0].split("(")[0][:70]
         print(f"{(r[1]-t0)/1e3:9.1f} us  dur {(r[2]-r[1])/1e3:8.1f} us  grid {r[3]}x{r[4]} wg {r[5]}  {name}")
-    print("== per-kernel stats over the whole run ==")
+    first = idx[warm] if 0 < warm < len(idx) else 0
+    print(f"== per-kernel stats over the {'timed steps (first ' + str(warm) + ' MSMs left out)' if first else 'whole run'} ==")
     agg = collections.defaultdict(list)
-    for r in rows:
+    for r in rows[first:]:
         agg[r[0].split("(")[0][:70]].append((r[2] - r[1]) / 1e3)
     tot = sum(sum(v) for v in agg.values())
     print(f"{'kernel':72s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
@@ -33,4 +39,4 @@ def main(path, as_markdown=False):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
