@@ -49,9 +49,35 @@ CTT_HD uint32_t scalar_bits_at(const uint32_t* k, int pos, int nb) {
   return lo & ((1u << nb) - 1u);
 }
 
-// digit of window w -> packed ((val-1)<<1 | neg) or DIGIT_NONE when val == 0
-CTT_HD uint32_t booth_digit_packed(const uint32_t* k, int w, int c) {
-  int i = w * c;
+// Window layout (round 3).  W windows cover bits + 1 bits of the scalar -- the spare top bit is always zero, so the top digit
+// never carries out and no window exists only for a carry -- with widths that differ by at most one: the first r windows (the
+// low bits) are cb + 1 bits wide, the others cb (r = 0: all cb).  Rounds 1-2 cut the scalar into bits/c windows of c bits plus
+// whatever remained (the reference's layout, ec_multi_scalar_mul.nim:278-289: 255 = 19 x 13 + 8): a top window of 8, 3 or 0 bits
+// sends its N digits into 128, 4 or 1 buckets -- head chains of hundreds of lanes for the merge tree (6 tree steps at 2^16
+// pairs, c = 13), one sort group that swallows N records, and window tables restricted to the few c with a wide remainder.
+// Any layout yields the same group element: sum_w 2^off(w) * sum_b digit_b B_b.
+struct WinLayout {
+  int cb, r;
+  CTT_HD int off(uint32_t w) const { return (int)w * cb + ((int)w < r ? (int)w : r); }
+  CTT_HD int width(uint32_t w) const { return cb + ((int)w < r ? 1 : 0); }
+  CTT_HD int cmax() const { return cb + (r > 0 ? 1 : 0); }
+  CTT_HD bool is_wide(uint32_t w) const { return r == 0 || (int)w < r; }   // as wide as the widest window
+};
+// W windows of at most c bits over bits + 1 bits
+CTT_HD WinLayout window_layout(int bits, int c, int* W) {
+  const int T = bits + 1;
+  const int nw = (T + c - 1) / c;
+  WinLayout L;
+  L.cb = T / nw;
+  L.r = T - L.cb * nw;
+  *W = nw;
+  return L;
+}
+
+// digit of window w -> packed ((val-1)<<1 | neg) or DIGIT_NONE when val == 0 (Booth signed digits, bigints.nim:806-859, over
+// the window's own width)
+CTT_HD uint32_t booth_digit_packed(const uint32_t* k, int w, const WinLayout& L) {
+  const int i = L.off((uint32_t)w), c = L.width((uint32_t)w);
   uint32_t d;
   if (i == 0) {
     d = (k[0] << 1) & ((1u << (c + 1)) - 1u);
@@ -70,14 +96,15 @@ CTT_HD uint32_t booth_digit_packed(const uint32_t* k, int w, int c) {
 // unrolled loop), so that the limbs are addressed with compile-time indices -- indexing k[] with the (wave-uniform, but
 // run-time) word of a window costs the GPU an 8-way select chain per access (measured: k_part_count 129 -> 78 us at 2^22).
 template <int NS, class Fn>
-CTT_HD void for_each_digit(const uint32_t (&k)[NS][8], uint32_t w0, uint32_t nw, int c, Fn&& fn) {
+CTT_HD void for_each_digit(const uint32_t (&k)[NS][8], uint32_t w0, uint32_t nw, const WinLayout& L, Fn&& fn) {
   uint32_t w = w0;
   const uint32_t wend = w0 + nw;
-  const uint32_t mask = (1u << (c + 1)) - 1u, vmask = (1u << c) - 1u;
 #pragma unroll
   for (int word = 0; word < 8; word++) {
     while (w < wend) {
-      const uint32_t i = w * (uint32_t)c;
+      const uint32_t i = (uint32_t)L.off(w);
+      const int c = L.width(w);
+      const uint32_t mask = (1u << (c + 1)) - 1u, vmask = (1u << c) - 1u;
       const uint32_t pos = i ? i - 1u : 0u;
       if ((pos >> 5) != (uint32_t)word) break;
       const uint32_t sh = pos & 31u;
@@ -111,14 +138,15 @@ CTT_HD void for_each_digit(const uint32_t (&k)[NS][8], uint32_t w0, uint32_t nw,
 struct SortArgs {
   const uint32_t* scalars;  // [n][8] canonical
   uint32_t n;
-  int c;
+  int c;                    // bits of the widest window: B = 2^(c-1)
+  WinLayout lay;            // widths and offsets of the digit windows
   uint32_t W, B;            // bucket sets, buckets per set
   uint32_t Wd;              // digit windows per scalar (== W unless merged)
   uint32_t merged;          // 1: every digit window goes to bucket set 0
   uint32_t nent;            // capacity of one set's entry list: n, or Wd*n when merged
   uint32_t id_stride;       // merged: table entries per window (>= n: a prefix of the cached bases may be used)
   uint32_t NG, gshift;      // bucket groups per set; group = bucket >> gshift
-  uint32_t gshift_top;      // same for the top window W-1, whose digits only reach 2^(bits - (W-1)c) buckets (== gshift when merged)
+  uint32_t gshift_narrow;   // same for the windows one bit narrower than c, whose digits only reach B/2 buckets (== gshift when merged)
   uint32_t slice, nblk;     // partition pass: scalars per block, number of blocks
   uint32_t jbits;           // bits of a point index: 32-bit record = low bucket bits << (jbits+1) | sign << jbits | index
   uint32_t* part;           // [W][nent] packed records partitioned by group (merged: 64-bit records, [nent])

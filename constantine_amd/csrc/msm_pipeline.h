@@ -25,7 +25,8 @@ struct MsmPlan {
   uint32_t slice;  // scalars per partition block
   uint32_t NG;     // bucket groups per window (sort pass A partitions by group, pass B sorts inside a group)
   uint32_t gshift; // group = bucket >> gshift
-  uint32_t gshift_top;  // the top window only reaches 2^tb buckets (tb = bits - (W-1)c): its groups are narrower
+  uint32_t gshift_narrow;  // windows one bit narrower than c only reach B/2 buckets: their groups are half as wide
+  WinLayout lay;       // widths / offsets of the W (Wd) digit windows; c = lay.cmax()
   uint32_t jbits;  // bits of a point index (sort records pack low bucket bits | sign | index into 32 bits)
   uint32_t cap, big;  // sort pass B: LDS tile entries; bucket size above which the LDS image is bypassed
   uint32_t K;      // sorted entries per accumulate lane
@@ -87,19 +88,19 @@ static inline uint32_t plan_entries_per_lane(uint32_t n, int W, uint32_t lanes) 
   return K;
 }
 
+// (c is the width asked for; the plan's windows are balanced: window_layout(), msm_bodies.h)
 static inline int choose_window_bits(uint32_t n, int bits, uint32_t lanes) {
   double best = 1e300;
   int bc = 8;
   for (int c = 6; c <= 16; c++) {
-    const int W = bits / c + 1;
-    const double B = (double)(1u << (c - 1));
+    int W;
+    const WinLayout L = window_layout(bits, c, &W);
+    const int cm = L.cmax();
+    const double B = (double)(1u << (cm - 1));
     const double K = (double)plan_entries_per_lane(n, W, lanes);
     const double acc = (double)W * n * 0.142e-3;
-    const double red = (c - 1) * 12.0 + 2.0 * B * W * 0.24e-3;
-    const int top = bits - (W - 1) * c;  // 0: the extra window only carries the Booth carry bit
-    const double top_buckets = top > 1 ? (double)(1u << (top - 1)) : 1.0;
-    double maxcnt = (double)n / top_buckets;
-    if (maxcnt < 2.0 * n / B) maxcnt = 2.0 * n / B;
+    const double red = (cm - 1) * 12.0 + 2.0 * B * W * 0.24e-3;
+    double maxcnt = 2.0 * n / (double)(1u << (L.cb - 1));   // the narrower windows fill 2^(cb-1) buckets; twice the mean
     double chain = maxcnt / K;
     int steps = 0;
     while (chain > 1.0) { chain *= 0.5; steps++; }
@@ -120,16 +121,18 @@ static inline void plan_horner(MsmPlan& p, const MsmOptions& o) {
   p.ngrp = horner_groups(p.c, h);
 }
 // Wide head-merge tree steps to enqueue: enough for the largest bucket an ordinary (uniform) digit distribution produces --
-// lambda entries per bucket on average, in the top window nent / 2^(top-1) (its digits only reach 2^(top-1) buckets; a
-// window table adds that to every bucket's share) -- with a margin of 6 sigma + 8; whatever an unusual input needs on top
-// of that is done by the merge-finish launch (one workgroup per window, msm_bodies.h merge_finish_body).
+// the mean of the fullest buckets (those of the narrower windows) with a margin of 6 sigma + 8; whatever an unusual input
+// needs on top of that is done by the merge-finish launch (one workgroup per window, msm_bodies.h merge_finish_body).
 static inline int plan_merge_steps(const MsmPlan& p, int bits) {
-  const double lam = (double)p.nent / (double)p.B;
-  const int top = bits - (p.Wd - 1) * p.c;
-  const double topb = top > 1 ? (double)(1u << (top - 1)) : 1.0;
-  double heavy = (double)p.n / topb;
-  if (p.merged) heavy += lam;
-  double m = heavy > lam ? heavy : lam;
+  (void)bits;
+  // entries per bucket: a window of width cw spreads its n digits over 2^(cw-1) buckets; the window table adds up all windows
+  const double narrow = (double)p.n / (double)(1u << (p.lay.cb - 1));
+  double m = narrow;
+  if (p.merged) {
+    const int wide = p.lay.r, nar = p.Wd - p.lay.r;   // (r = 0: every window has cb bits and counts as narrow here)
+    m = (double)p.n * ((double)wide + 2.0 * (double)nar) / (double)p.B;
+    if (p.lay.r == 0) m = (double)p.n * (double)p.Wd / (double)p.B;
+  }
   double sd = 1.0;
   while (sd * sd < m) sd += 1.0;
   m += 6.0 * sd + 8.0;
@@ -152,7 +155,10 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
     while (jb < 31 && (1ull << jb) < n) jb++;
     while (p.c > 2 && (int)jb + 1 + (p.c - 1 - 12) > 32) p.c--;
   }
-  p.W = bits / p.c + 1;  // ec_multi_scalar_mul_parallel.nim:157-158: one more window when c | bits
+  // balanced windows over bits + 1 bits (msm_bodies.h WinLayout); the reference's count, bits/c + 1 windows when c | bits
+  // (ec_multi_scalar_mul_parallel.nim:157-158), comes out of the same formula
+  p.lay = window_layout(bits, p.c, &p.W);
+  p.c = p.lay.cmax();
   p.B = 1u << (p.c - 1);
   // sort pass A: ~512 partition blocks of at least 2048 scalars; pass B: groups of ~16384 entries (one workgroup
   // sorts a group inside LDS), at most 4096 buckets per group (LDS counters)
@@ -179,13 +185,7 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   while ((p.B >> p.gshift) > NG) p.gshift++;
   while (p.gshift > 0 && p.jbits + 1 + p.gshift > 32) { p.gshift--; NG <<= 1; }
   p.NG = NG;
-  {
-    const uint32_t tb = (uint32_t)(bits - (p.W - 1) * p.c);  // significant bits of the top window, 0 .. c-1
-    uint32_t lg = 0;
-    while ((1u << lg) < NG) lg++;
-    p.gshift_top = tb > lg ? tb - lg : 0u;
-    if (p.gshift_top > p.gshift) p.gshift_top = p.gshift;
-  }
+  p.gshift_narrow = (p.lay.r > 0 && p.gshift > 0) ? p.gshift - 1 : p.gshift;
   // entries per lane: fill the resident lanes once
   uint32_t K = o.K > 0 ? (uint32_t)o.K : plan_entries_per_lane(n, p.W, o.lanes);
   K = (K + 3u) & ~3u;
@@ -211,40 +211,35 @@ static inline int table_index_bits(uint64_t rows) {
   return jb;
 }
 static inline bool table_plan_fits(uint32_t ntab, int bits, int c) {
-  const int Wd = bits / c + 1;
+  int Wd;
+  (void)window_layout(bits, c, &Wd);
   const uint64_t rows = (uint64_t)Wd * ntab;   // an entry is a table row | sign << 31
   return rows <= 0x7fffffffull && Wd <= 128;
 }
 static inline int choose_table_window_bits(uint32_t ntab, int bits) {
-  // Same constants as choose_window_bits, one bucket set.  What differs is the top window: its digits only reach 2^top
-  // buckets (top = bits - (Wd-1)*c), and in the shared bucket set those buckets receive N/2^top entries on top of their
-  // share -- long head chains for the merge tree, and one bucket group that a single sort workgroup has to swallow
-  // (measured, BLS12-381 G1 2^20 bases: c = 20, top = 15: sort 0.29 ms, 2.68 ms per MSM; c = 19, top = 8: sort 0.68 ms,
-  // 3.17 ms; c = 21, top = 3: sort 1.39 ms, 4.42 ms).
+  // Same constants as choose_window_bits, one bucket set: 2*2^(c-1) additions of reduction in total, not per window, so c
+  // grows until those balance the Wd*N accumulations.  With balanced windows (round 3) the windows one bit narrower than
+  // c fill only the lower half of the shared buckets -- twice the mean there, nothing worse: round 2's layout put all N
+  // digits of a narrow top window into 2^top buckets and restricted the table to the few c with a wide remainder
+  // (measured then, BLS12-381 G1 2^20: c = 20 2.68 ms per MSM, c = 19 3.17 ms, c = 21 4.42 ms).
   double best = 1e300;
   int bc = 0;
   for (int c = 4; c <= 22; c++) {
     if (!table_plan_fits(ntab, bits, c)) continue;
-    const int Wd = bits / c + 1;
-    const double B = (double)(1u << (c - 1));
+    int Wd;
+    const WinLayout L = window_layout(bits, c, &Wd);
+    const int cm = L.cmax();
+    const double B = (double)(1u << (cm - 1));
     const double total = (double)Wd * ntab;
     const double K = (double)plan_entries_per_lane((uint32_t)(total > 4e9 ? 4e9 : total), 1, 131072);
     const double acc = total * 0.142e-3;
-    const double red = (c - 1) * 12.0 + 2.0 * B * 0.24e-3;
-    const int top = bits - (Wd - 1) * c;
-    const double top_buckets = top > 0 ? (double)(1u << top) : 1.0;
-    double maxcnt = (double)ntab / top_buckets + total / B;
+    const double red = (cm - 1) * 12.0 + 2.0 * B * 0.24e-3;
+    const double maxcnt = 2.0 * (L.r ? (double)ntab * (L.r + 2.0 * (Wd - L.r)) / B : total / B);
     double chain = maxcnt / K;
     int steps = 0;
     while (chain > 1.0) { chain *= 0.5; steps++; }
     const double mer = 45.0 + 28.0 * steps;
-    // the heaviest bucket group: groups of ~12288 records (make_table_plan), the top window's records on top
-    double groups = 1.0;
-    while (groups * 12288.0 < total && groups < 4096.0) groups *= 2.0;
-    while (B / groups > 1024.0) groups *= 2.0;
-    const double group_buckets = B / groups;
-    const double heavy = (double)ntab * (group_buckets < top_buckets ? group_buckets / top_buckets : 1.0);  // extra records of the heaviest group
-    const double srt = total * 0.02e-3 + 60.0 + heavy * 0.8e-3;
+    const double srt = total * 0.02e-3 + 60.0;
     const double cost = acc + red + mer + srt;
     if (cost < best) { best = cost; bc = c; }
   }
@@ -255,10 +250,10 @@ static inline int choose_table_window_bits(uint32_t ntab, int bits) {
 static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab, const MsmOptions& o) {
   MsmPlan p;
   p.n = n;
-  p.c = c;
-  p.Wd = bits / c + 1;
+  p.lay = window_layout(bits, c, &p.Wd);
+  p.c = p.lay.cmax();
   p.W = 1;
-  p.B = 1u << (c - 1);
+  p.B = 1u << (p.c - 1);
   p.merged = 1;
   p.nent = (uint32_t)((uint64_t)p.Wd * n);
   p.id_stride = ntab;
@@ -270,14 +265,16 @@ static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab
   p.big = 1024u;
   // bucket groups of ~12288 records over all windows (the groups of the top window's buckets receive its records on top, and
   // a group of up to 20480 is sorted in one sweep), at most 1024 buckets per group, and the packed record must fit 32 bits
+  // (the narrower windows only reach the lower half of the buckets: the groups there hold `heavy` records between them)
+  const uint64_t heavy = p.lay.r ? 2ull * ((uint64_t)p.nent - (uint64_t)p.lay.r * n / 2u) : (uint64_t)p.nent;
   uint32_t NG = 1;
-  while ((uint64_t)NG * 12288u < p.nent && NG < 4096u) NG <<= 1;
+  while ((uint64_t)NG * 12288u < heavy && NG < 4096u) NG <<= 1;
   while (NG < p.B && p.B / NG > 1024u) NG <<= 1;
   if (NG > p.B) NG = p.B;
   p.gshift = 0;
   while ((p.B >> p.gshift) > NG) p.gshift++;
   p.NG = NG;
-  p.gshift_top = p.gshift;  // all windows share the groups
+  p.gshift_narrow = p.gshift;  // all windows share the groups
   uint32_t K = o.K > 0 ? (uint32_t)o.K : plan_entries_per_lane(p.nent, 1, o.lanes);
   K = (K + 3u) & ~3u;
   if (K < 4) K = 4;
@@ -309,11 +306,13 @@ CTT_HD XYZZ<F> window_group_sum_body(const XYZZ<F>* ow, int c, int h, int g) {
   return r;
 }
 template <class F>
-static inline XYZZ<F> combine_groups(const XYZZ<F>* s, int W, int c, int h, int ngrp) {
+static inline XYZZ<F> combine_groups(const XYZZ<F>* s, int W, const WinLayout& L, int h, int ngrp) {
   XYZZ<F> r = XYZZ<F>::inf();
   for (int w = W - 1; w >= 0; w--) {
+    // window w+1 starts width(w) bits above window w: those doublings are spread over the groups of window w
+    const int cw = L.width((uint32_t)w);
     for (int g = ngrp - 1; g >= 0; g--) {
-      const int nd = g == ngrp - 1 ? c - g * h : h;
+      const int nd = g == ngrp - 1 ? cw - g * h : h;
       for (int l = 0; l < nd; l++) r = xyzz_dbl<F>(r);
       xyzz_add<F>(r, s[(size_t)w * ngrp + g]);
     }
@@ -402,7 +401,8 @@ struct MsmEngine {
     if (c < 2 || c > 22 || !table_plan_fits(n, C::BITS, c)) c = choose_table_window_bits(n, C::BITS);
     *c_out = c;
     if (n == 0 || c == 0) return nullptr;
-    const int Wd = C::BITS / c + 1;
+    int Wd;
+    const WinLayout lay = window_layout(C::BITS, c, &Wd);
     const size_t stride = kConvert ? (size_t)gather_stride<FD>() : sizeof(Affine<F>);
     char* tab = nullptr;
     Affine<F>* lvl[2] = {nullptr, nullptr};
@@ -421,7 +421,7 @@ struct MsmEngine {
     for (int w = 0; w < Wd; w++) {
       if (w > 0) {
         Affine<F>* nxt = lvl[w & 1];
-        bk.template launch_table_next<F>(cur, nxt, n, c);
+        bk.template launch_table_next<F>(cur, nxt, n, lay.width((uint32_t)w - 1));   // level w = 2^width(w-1) x level w-1
         cur = nxt;
       }
       if constexpr (kConvert) bk.template launch_convert<F, FD>(cur, tab + (size_t)w * n * stride, n);
@@ -493,9 +493,9 @@ struct MsmEngine {
     bk.stage_begin(sl, ST_SORT);
     SortArgs sa;
     sa.scalars = d_scalars;
-    sa.n = n; sa.c = p.c; sa.W = W; sa.B = B;
+    sa.n = n; sa.c = p.c; sa.lay = p.lay; sa.W = W; sa.B = B;
     sa.Wd = (uint32_t)p.Wd; sa.merged = p.merged; sa.nent = p.nent; sa.id_stride = p.id_stride;
-    sa.NG = p.NG; sa.gshift = p.gshift; sa.gshift_top = p.gshift_top; sa.slice = p.slice; sa.nblk = p.S;
+    sa.NG = p.NG; sa.gshift = p.gshift; sa.gshift_narrow = p.gshift_narrow; sa.slice = p.slice; sa.nblk = p.S;
     sa.jbits = p.jbits;
     sa.cap = p.cap; sa.big = p.big;
     sa.part = (uint32_t*)need(part, (size_t)W * p.nent * (p.merged ? 8 : 4));
@@ -749,7 +749,7 @@ struct MsmEngine {
     const size_t cnt = (size_t)p.W * p.ngrp;
     std::vector<XYZZ<HF>> sums(cnt);
     for (size_t i = 0; i < cnt; i++) sums[i] = xyzz_to_host<FD>(raw[i]);
-    return combine_groups<HF>(sums.data(), p.W, p.c, p.h, p.ngrp);
+    return combine_groups<HF>(sums.data(), p.W, p.lay, p.h, p.ngrp);
   }
 
   bool in_flight(int sl) const { return sl >= 0 && sl < 2 && slots[sl].busy; }

@@ -16,17 +16,20 @@ int main() {
         if (c == 1) continue;
         o.c = c;
         const MsmPlan p = make_plan((uint32_t)n, bits, o);
-        bool ok = p.c >= 2 && p.c <= 16 && (c == 0 || p.c <= c) && p.W == bits / p.c + 1 && p.B == (1u << (p.c - 1));
+        // balanced windows over bits + 1 bits: r windows of cb + 1 bits, the others cb; c is the widest
+        bool ok = p.c >= 2 && p.c <= 16 && (c == 0 || p.c <= c) && p.B == (1u << (p.c - 1));
+        ok = ok && p.lay.cb * p.W + p.lay.r == bits + 1 && p.lay.r >= 0 && p.lay.r < p.W && p.c == p.lay.cmax();
+        ok = ok && p.lay.off((uint32_t)p.W - 1) + p.lay.width((uint32_t)p.W - 1) == bits + 1 && p.lay.off(0) == 0;
         ok = ok && p.NG >= 1 && p.NG <= 4096 && p.NG <= p.B && (p.B >> p.gshift) == p.NG && p.B / p.NG <= 1024;
-        ok = ok && p.jbits + 1 + p.gshift <= 32 && (1ull << p.jbits) >= n && p.gshift_top <= p.gshift;
+        ok = ok && p.jbits + 1 + p.gshift <= 32 && (1ull << p.jbits) >= n && p.gshift_narrow <= p.gshift;
         ok = ok && (unsigned long long)p.S * p.slice >= n && (unsigned long long)(p.S - 1) * p.slice < n;
         ok = ok && p.K >= 4 && (unsigned long long)p.G * p.K >= n && (unsigned long long)(p.G - 1) * p.K < n;
-        const unsigned tb = (unsigned)(bits - (p.W - 1) * p.c);
-        ok = ok && ((1ull << tb) >> p.gshift_top) <= p.NG;  // every reachable bucket of the top window has a group
+        // every reachable bucket of a narrower window (2^(cb-1) of them) has a group
+        ok = ok && (p.lay.r == 0 || ((1ull << (p.lay.cb - 1)) >> p.gshift_narrow) <= p.NG);
         if (!ok) {
           bad++;
           printf("BAD bits=%d n=%llu c_req=%d -> c=%d W=%d B=%u NG=%u gshift=%u/%u jbits=%u slice=%u S=%u K=%u G=%u\n", bits, n, c,
-                 p.c, p.W, p.B, p.NG, p.gshift, p.gshift_top, p.jbits, p.slice, p.S, p.K, p.G);
+                 p.c, p.W, p.B, p.NG, p.gshift, p.gshift_narrow, p.jbits, p.slice, p.S, p.K, p.G);
         }
       }
     }

@@ -95,7 +95,7 @@ def plan(n, bits, lanes, table_c=0, ntab=0):
     L = lib()
     L.emu_plan.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
     L.emu_plan(n, bits, lanes, table_c, ntab, _p(out))
-    return dict(zip(("c", "W", "Wd", "B", "K", "G", "S", "slice", "NG", "gshift", "nent"), (int(x) for x in out)))
+    return dict(zip(("c", "W", "Wd", "B", "K", "G", "S", "slice", "NG", "gshift", "nent", "cb", "r", "merge_steps"), (int(x) for x in out)))
 
 
 def table_window_bits(ntab, bits):

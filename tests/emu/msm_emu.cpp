@@ -71,9 +71,9 @@ struct EmuBackend {
       for (uint32_t j = 0; j < n; j++) {
         uint32_t k[1][8];
         for (int q = 0; q < 8; q++) k[0][q] = a.scalars[8ull * j + q];
-        for_each_digit<1>(k, 0, a.Wd, a.c, [&](uint32_t w, const uint32_t (&dd)[1]) {
+        for_each_digit<1>(k, 0, a.Wd, a.lay, [&](uint32_t w, const uint32_t (&dd)[1]) {
           const uint32_t d = dd[0];
-          if (d != booth_digit_packed(a.scalars + 8ull * j, (int)w, a.c)) abort();
+          if (d != booth_digit_packed(a.scalars + 8ull * j, (int)w, a.lay)) abort();
           all[(size_t)w * n + j] = d;
           if (d != DIGIT_NONE) cnt[d >> 1]++;
         });
@@ -99,8 +99,8 @@ struct EmuBackend {
         dg[j] = DIGIT_NONE;
         uint32_t k[1][8];
         for (int q = 0; q < 8; q++) k[0][q] = a.scalars[8ull * j + q];
-        for_each_digit<1>(k, w, 1, a.c, [&](uint32_t, const uint32_t (&dd)[1]) { dg[j] = dd[0]; });   // the GPU kernels' digit walker
-        if (dg[j] != booth_digit_packed(a.scalars + 8ull * j, (int)w, a.c)) abort();
+        for_each_digit<1>(k, w, 1, a.lay, [&](uint32_t, const uint32_t (&dd)[1]) { dg[j] = dd[0]; });   // the GPU kernels' digit walker
+        if (dg[j] != booth_digit_packed(a.scalars + 8ull * j, (int)w, a.lay)) abort();
         if (dg[j] != DIGIT_NONE) cnt[dg[j] >> 1]++;
       }
       uint32_t* bs = a.bstart + (size_t)w * (B + 1);
@@ -362,13 +362,14 @@ int emu_msm_host(int curve, int coef_is_fr, int out_kind, void* r, const void* c
   const EmuOps* o = ops_of(curve);
   return o ? o->msm_host(coef_is_fr, out_kind, r, coefs, points, n, c, chunks) : -1;
 }
-// the plan the engine would make (msm_pipeline.h make_plan / make_table_plan): c, W, Wd, B, K, G, S, slice, NG, gshift, nent
+// the plan the engine would make (msm_pipeline.h make_plan / make_table_plan): c, W, Wd, B, K, G, S, slice, NG, gshift, nent, cb, r, merge steps
 int emu_plan(uint32_t n, int bits, uint32_t lanes, int table_c, uint32_t ntab, uint32_t* out) {
   MsmOptions o;
   o.lanes = lanes;
   const MsmPlan p = table_c > 0 ? make_table_plan(n, bits, table_c, ntab, o) : make_plan(n, bits, o);
   out[0] = (uint32_t)p.c; out[1] = (uint32_t)p.W; out[2] = (uint32_t)p.Wd; out[3] = p.B; out[4] = p.K; out[5] = p.G;
   out[6] = p.S; out[7] = p.slice; out[8] = p.NG; out[9] = p.gshift; out[10] = p.nent;
+  out[11] = (uint32_t)p.lay.cb; out[12] = (uint32_t)p.lay.r; out[13] = (uint32_t)p.merge_steps;
   return 0;
 }
 int emu_table_window_bits(uint32_t ntab, int bits) { return choose_table_window_bits(ntab, bits); }

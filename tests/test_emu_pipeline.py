@@ -354,7 +354,7 @@ def test_window_table_falls_back_when_memory_or_window_bits_do_not_fit(monkeypat
     pts = cref.gen_points(name, 923, n)
     sc = cref.synth_scalars(924, n, 255)
     expect, _ = cref.msm(name, sc, pts)
-    monkeypatch.setenv("EMU_ALLOC_LIMIT", str(2 << 20))      # the table (>= 12 levels of n records: > 3 MiB) does not fit, the rest does
+    monkeypatch.setenv("EMU_ALLOC_LIMIT", str(3 << 20))      # the table (>= 12 levels of n records: > 3 MiB) does not fit, the rest does
     out, cu = emu.msm_table(name, sc, pts, c=0)
     assert cu == 0 and bytes(out) == bytes(expect)
 
@@ -370,7 +370,9 @@ def test_plan_fits_the_gpu_for_any_size():
     for n in sizes:
         for bits, lanes in ((255, 131072), (254, 262144), (255, 65536)):
             p = emu.plan(n, bits, lanes)
-            assert p["W"] == bits // p["c"] + 1 and p["Wd"] == p["W"] and p["nent"] == n
+            # balanced windows over bits + 1 bits: r of cb + 1 bits, the others cb; c is the widest
+            assert p["cb"] * p["W"] + p["r"] == bits + 1 and 0 <= p["r"] < p["W"] and p["c"] == p["cb"] + (1 if p["r"] else 0)
+            assert p["Wd"] == p["W"] and p["nent"] == n and p["B"] == 1 << (p["c"] - 1)
             assert p["G"] == -(-n // p["K"]) and p["K"] % 4 == 0
             assert p["W"] * -(-p["G"] // 64) <= max(lanes // 64, p["W"]), (n, bits, lanes, p)
             assert p["S"] == -(-n // p["slice"]) and p["S"] <= 520, (n, p)
@@ -378,7 +380,8 @@ def test_plan_fits_the_gpu_for_any_size():
             c = emu.table_window_bits(n, bits)
             assert 4 <= c <= 22
             t = emu.plan(n, bits, lanes, table_c=c, ntab=n)
-            assert t["W"] == 1 and t["Wd"] == bits // c + 1 and t["nent"] == t["Wd"] * n
+            assert t["W"] == 1 and t["Wd"] == -(-(bits + 1) // c) and t["nent"] == t["Wd"] * n
+            assert t["cb"] * t["Wd"] + t["r"] == bits + 1 and t["c"] <= c
             assert -(-t["G"] // 64) <= max(lanes // 64, 1), (n, bits, lanes, t)
             assert t["G"] == -(-t["nent"] // t["K"])
             assert t["NG"] <= 16384 and t["B"] // t["NG"] <= 1024
