@@ -48,6 +48,9 @@ struct MsmOptions {
   int host_window_sums = 0;  // legacy spelling of horner_bits: 1 = 1 bit per group (the whole bit Horner on the host),
                              // 2 = one group per window (the whole bit Horner on the device), 0 = horner_bits decides
   int horner_bits = 0;       // bits per group of the bit Horner the device runs (0 = choose: 4); see plan_horner
+  // cost model of the window choice: ns per mixed addition (accumulate) / per full addition (reduction) with the chip busy;
+  // the engine fills in its curve's figures (msm_bodies.h curve descriptors), the defaults are BLS12-381 G1's
+  double acc_ns = 0.142, red_ns = 0.26;
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -89,22 +92,29 @@ static inline uint32_t plan_entries_per_lane(uint32_t n, int W, uint32_t lanes) 
 }
 
 // (c is the width asked for; the plan's windows are balanced: window_layout(), msm_bodies.h)
-static inline int choose_window_bits(uint32_t n, int bits, uint32_t lanes) {
+// Round-3 re-fit with balanced windows and per-curve constants, against one box's sweeps (gpurun_out/r3d -> profiles/
+// sweep_window_bits_r03.jsonl; ms per MSM with two in flight): the model's choice is the measured best or within 3 % of it
+// for BLS12-381 G1 2^12 .. 2^22 (13, 13, 13, 13/14, 14, 16, 16, 16), G2 2^16 .. 2^20, BN254 2^16 .. 2^22, Pallas 2^16 / 2^20.
+// A latency term is weighted by the curve's addition time (a pass of the reduction is one addition deep).
+static inline int choose_window_bits(uint32_t n, int bits, uint32_t lanes, double acc_ns = 0.142, double red_ns = 0.26) {
   double best = 1e300;
   int bc = 8;
-  for (int c = 6; c <= 16; c++) {
+  const double ratio = acc_ns / 0.142;
+  // (c = 17, 18 only pay from ~2^23 pairs on -- measured BLS12-381 G1 2^24: 15 windows of 17-18 bits 41.3 ms per MSM against
+  // 43.6 ms for 16 windows of 16, 2^22: 11.5 against 10.9 -- and the sort's 32-bit records hold c <= 44 - bits(n), see make_plan)
+  for (int c = 6; c <= 18; c++) {
     int W;
     const WinLayout L = window_layout(bits, c, &W);
     const int cm = L.cmax();
     const double B = (double)(1u << (cm - 1));
     const double K = (double)plan_entries_per_lane(n, W, lanes);
-    const double acc = (double)W * n * 0.142e-3;
-    const double red = (cm - 1) * 12.0 + 2.0 * B * W * 0.24e-3;
+    const double acc = (double)W * n * acc_ns * 1e-3;
+    const double red = (cm - 1) * 8.0 * ratio + 2.0 * B * W * red_ns * 1e-3;
     double maxcnt = 2.0 * n / (double)(1u << (L.cb - 1));   // the narrower windows fill 2^(cb-1) buckets; twice the mean
     double chain = maxcnt / K;
     int steps = 0;
     while (chain > 1.0) { chain *= 0.5; steps++; }
-    const double mer = 45.0 + 28.0 * steps;
+    const double mer = (45.0 + 28.0 * steps) * ratio;
     const double srt = (double)W * n * 0.02e-3 + 60.0;
     const double cost = acc + red + mer + srt;
     if (cost < best) { best = cost; bc = c; }
@@ -145,9 +155,9 @@ static inline int plan_merge_steps(const MsmPlan& p, int bits) {
 static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   MsmPlan p;
   p.n = n;
-  p.c = o.c > 0 ? o.c : choose_window_bits(n, bits, o.lanes);
+  p.c = o.c > 0 ? o.c : choose_window_bits(n, bits, o.lanes, o.acc_ns, o.red_ns);
   if (p.c < 2) p.c = 2;
-  if (p.c > 16) p.c = 16;
+  if (p.c > 20) p.c = 20;   // (the automatic choice stays <= 18; wider windows on request: 2^19 buckets per window at most)
   {
     // the sort packs (low bucket bits | sign | point index) into 32 bits with at most 4096 bucket groups per window:
     // beyond 2^28 pairs that caps the window width (c <= 44 - bits(n): 15 at 2^29, 13 at 2^31)
@@ -573,17 +583,20 @@ struct MsmEngine {
     // The narrow passes at the end, the bit Horner and the result copy move to the backend's tail stream: they are
     // latency-bound and the next MSM's conversion and sort fit underneath them (the tail_wait() before the accumulation also
     // orders the previous tail before this MSM's first write to the pyramid buffers).
+    // (only for a caller that keeps MSMs in flight -- the other slot is busy: a lone blocking call would pay the fork's
+    // event record and wait, ~15 us, for nothing)
+    const bool pipelining = slots[sl ^ 1].busy;
     bool forked = false;
     for (int pass = 0; pass <= p.c - 2; pass++) {
       PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass, 1u};
       const uint32_t ntasks = pyr_pass_tasks(B, p.c, pass);
-      if (!forked && pass > 0 && bk.pyr_goes_to_tail(ntasks, W)) {
+      if (pipelining && !forked && pass > 0 && bk.pyr_goes_to_tail(ntasks, W)) {
         bk.tail_begin();
         forked = true;
       }
       bk.template launch_pyr<FD>(pa, W, ntasks);
     }
-    if (!forked) {
+    if (pipelining && !forked) {
       bk.tail_begin();
       forked = true;
     }
@@ -598,7 +611,7 @@ struct MsmEngine {
     }
     bk.d2h_async(sl, S.hraw, d_wsum, bytes);
     bk.stage_end(sl, ST_TOTAL);
-    bk.tail_end();
+    if (forked) bk.tail_end();
   }
 
   int claim_slot(uint32_t n) {
@@ -619,7 +632,15 @@ struct MsmEngine {
              const void* d_prepared = nullptr, int table_c = 0, uint32_t table_n = 0) {
     const int sl = claim_slot(n);
     if (sl < 0 || n == 0) return sl;
-    const MsmPlan p = table_c > 0 ? make_table_plan(n, C::BITS, table_c, table_n, opt) : make_plan(n, C::BITS, opt);
+    opt.acc_ns = C::ACC_NS;
+    opt.red_ns = C::RED_NS;
+    MsmOptions po = opt;
+    // A caller that keeps MSMs in flight gets the narrow tail of the previous MSM (last reduction passes, bit Horner, result
+    // copy: ~0.15 ms of latency, a handful of waves) run BESIDE this accumulation when the accumulate grid leaves wave slots
+    // free (accumulate_pairs); for small MSMs it pays to leave them free on purpose -- a sixth of the lanes, K grows by a
+    // fifth (measured, BLS12-381 G1 2^17, ms per MSM with two in flight: 0.69 with 17 % of the slots free, 0.80 with 5 %).
+    if (slots[sl ^ 1].busy && n <= (1u << 17) && opt.K <= 0) po.lanes = (uint32_t)((uint64_t)opt.lanes * 27u / 32u);
+    const MsmPlan p = table_c > 0 ? make_table_plan(n, C::BITS, table_c, table_n, po) : make_plan(n, C::BITS, po);
     slots[sl].plan = p;
     last_plan = p;
     try {
@@ -688,8 +709,10 @@ struct MsmEngine {
     }
     uint32_t largest = 0;
     for (uint32_t i = 0; i < nch; i++) largest = bound[i + 1] - bound[i] > largest ? bound[i + 1] - bound[i] : largest;
+    opt.acc_ns = C::ACC_NS;
+    opt.red_ns = C::RED_NS;
     MsmOptions o = opt;
-    if (o.c <= 0) o.c = choose_window_bits(n, C::BITS, o.lanes);  // one window size for the whole MSM
+    if (o.c <= 0) o.c = choose_window_bits(n, C::BITS, o.lanes, o.acc_ns, o.red_ns);  // one window size for the whole MSM
     try {
     bk.stage_begin(sl, ST_TOTAL);
     const MsmPlan p0 = make_plan(largest, C::BITS, o);   // the largest slice sizes the workspace

@@ -12,12 +12,12 @@ int main() {
                                       1ull << 30, (1ull << 31) - 1};
   for (int bits : {254, 255}) {
     for (unsigned long long n : sizes) {
-      for (int c = 0; c <= 16; c++) {
+      for (int c = 0; c <= 20; c++) {
         if (c == 1) continue;
         o.c = c;
         const MsmPlan p = make_plan((uint32_t)n, bits, o);
         // balanced windows over bits + 1 bits: r windows of cb + 1 bits, the others cb; c is the widest
-        bool ok = p.c >= 2 && p.c <= 16 && (c == 0 || p.c <= c) && p.B == (1u << (p.c - 1));
+        bool ok = p.c >= 2 && p.c <= (c == 0 ? 18 : 20) && (c == 0 || p.c <= c) && p.B == (1u << (p.c - 1));
         ok = ok && p.lay.cb * p.W + p.lay.r == bits + 1 && p.lay.r >= 0 && p.lay.r < p.W && p.c == p.lay.cmax();
         ok = ok && p.lay.off((uint32_t)p.W - 1) + p.lay.width((uint32_t)p.W - 1) == bits + 1 && p.lay.off(0) == 0;
         ok = ok && p.NG >= 1 && p.NG <= 4096 && p.NG <= p.B && (p.B >> p.gshift) == p.NG && p.B / p.NG <= 1024;

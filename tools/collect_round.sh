@@ -18,15 +18,26 @@ timeout 600 python bench.py > "$OUT/bench_$TAG.json" 2> "$OUT/bench.err"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o p -- python "$REPO/bench.py" --steps 10 --warmup 2 \
     --no-cpu-baseline --no-latency > "$OUT/bench_${TAG}_under_rocprof.json" 2> "$OUT/prof.log" )
 DB=$(find "$OUT/prof" -name "*.db" | head -1)
-python tools/kernel_timeline.py "$DB" > "$OUT/rocprof_${TAG}_kernel_stats.txt" 2>> "$OUT/prof.log"
+python tools/kernel_timeline.py "$DB" 2 > "$OUT/rocprof_${TAG}_kernel_stats.txt" 2>> "$OUT/prof.log"   # (2: the warm-up MSMs are left out of the averages)
 
-# HBM traffic: one counter per pass, csv output, kernel-trace only
-for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o p -- python "$REPO/bench.py" \
-      --steps 3 --warmup 1 --no-cpu-baseline --no-latency > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.log" )
-done
-python tools/pmc_summary.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "bls12_381_g1_2^20" "$OUT/hbm_traffic_k_accum.json" \
-    "$OUT/pmc_${TAG}_hbm_bytes.txt" > /dev/null 2>> "$OUT/prof.log"
+# HBM traffic of every config the bench prints a roofline for: one counter per pass, csv output, kernel-trace only
+hbm() {  # key, bench args...
+  local key=$1; shift
+  local tag=$(echo "$key" | tr '^' 'p')
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_${c}_$tag" -o p -- python "$REPO/bench.py" \
+        --steps 3 --warmup 1 --no-cpu-baseline --no-latency "$@" > /dev/null 2> "$OUT/pmc_${c}_$tag.log" )
+  done
+  python tools/pmc_summary.py "$OUT/pmc_FETCH_SIZE_$tag" "$OUT/pmc_WRITE_SIZE_$tag" "$key" "$OUT/hbm_traffic_k_accum.json" \
+      "$OUT/pmc_${TAG}_hbm_bytes_$tag.txt" > /dev/null 2>> "$OUT/prof.log"
+  rm -rf "$OUT/pmc_FETCH_SIZE_$tag" "$OUT/pmc_WRITE_SIZE_$tag"
+}
+hbm "bls12_381_g1_2^20"
+hbm "bls12_381_g1_2^22" --log2n 22
+hbm "bls12_381_g1_2^24" --log2n 24
+hbm "bn254_snarks_g1_2^22" --curve bn254_snarks_g1 --log2n 22
+hbm "pallas_2^20" --curve pallas
+hbm "bls12_381_g2_2^20" --curve bls12_381_g2
 
 # SQ counters of the accumulate kernel (own passes, kernel-trace only) for the headline and the 254/255-bit fields,
 # and the kernel statistics of those configs
@@ -41,12 +52,12 @@ sq() {  # tag, mixed adds per launch, bench args...
 sq bls12_381_g1_2pow20 16777216
 sq bn254_snarks_g1_2pow22 67108864 --curve bn254_snarks_g1 --log2n 22
 sq pallas_2pow20 16777216 --curve pallas
-for cfg in "bn254_snarks_g1 22" "pallas 20" "bls12_381_g2 20"; do
+for cfg in "bn254_snarks_g1 22" "pallas 20" "bls12_381_g2 20" "bls12_381_g1 16" "bls12_381_g1 18"; do
   set -- $cfg
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_$1" -o p -- python "$REPO/bench.py" --curve $1 --log2n $2 --steps 10 --warmup 2 \
       --no-cpu-baseline --no-latency > /dev/null 2>> "$OUT/prof.log" )
   DB=$(find "$OUT/prof_$1" -name "*.db" | head -1)
-  python tools/kernel_timeline.py "$DB" > "$OUT/rocprof_${TAG}_kernel_stats_$1_2pow$2.txt" 2>> "$OUT/prof.log"
+  python tools/kernel_timeline.py "$DB" 2 > "$OUT/rocprof_${TAG}_kernel_stats_$1_2pow$2.txt" 2>> "$OUT/prof.log"
   find "$OUT/prof_$1" -name "*.db" -delete 2>/dev/null
 done
 
@@ -59,6 +70,10 @@ for k in 16 17 18 19 22 24; do
   timeout 300 python bench.py --log2n $k --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g1_2pow$k.json" 2>> "$OUT/bench.err"
 done
 timeout 300 python tools/bench_batch_ops.py > "$OUT/batch_ops_$TAG.txt" 2>> "$OUT/bench.err"
+timeout 200 tools/microbench_inv.bin > "$OUT/microbench_inv_$TAG.jsonl" 2>> "$OUT/bench.err"
+timeout 300 python tools/sweep.py bls12_381_g1 10 c=0 -- bls12_381_g1 12 c=0 -- bls12_381_g1 14 c=0 -- bls12_381_g1 16 c=0 -- bls12_381_g1 17 c=0 -- bls12_381_g1 18 c=0 -- bls12_381_g1 19 c=0 \
+    -- bls12_381_g1 20 c=0 -- bls12_381_g1 22 c=0 -- bls12_381_g1 24 c=0 -- bls12_381_g2 18 c=0 -- bls12_381_g2 20 c=0 -- bn254_snarks_g1 16 c=0 -- bn254_snarks_g1 20 c=0,16,17 -- bn254_snarks_g1 22 c=0 \
+    -- pallas 20 c=0 -- vesta 20 c=0 -- bn254_snarks_g2 18 c=0 > "$OUT/sweep_sizes_$TAG.jsonl" 2>> "$OUT/bench.err"
 timeout 300 python tools/bench_hostptr.py > "$OUT/hostptr_$TAG.txt" 2>> "$OUT/bench.err"
 # cached bases with a window table next to the plain records (same box, same inputs): ms per pipelined step + stage times
 {
