@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTT_MSM_HIP_LIB") or os.path.join(HERE, "libctt_msm_hip.so")
 
 _lib = None
-ABI_VERSION = 4  # ctt_hip_msm_abi_version() of the library this package was written against
+ABI_VERSION = 5  # ctt_hip_msm_abi_version() of the library this package was written against
 
 
 class HipLibraryMissing(RuntimeError):
@@ -28,7 +28,7 @@ def exported_symbols():
              "ctt_hip_msm_device", "ctt_hip_msm_device_submit", "ctt_hip_msm_device_finish", "ctt_hip_msm_sync", "ctt_hip_msm_bases_create", "ctt_hip_msm_bases_destroy",
              "ctt_hip_msm_with_bases", "ctt_hip_msm_with_bases_submit", "ctt_hip_msm_bases_create_table", "ctt_hip_msm_bases_window_bits", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
              "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream", "ctt_hip_msm_wait_stream",
-             "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min", "ctt_hip_subgroup_check"]
+             "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min", "ctt_hip_subgroup_check", "ctt_hip_fr_quotient"]
     return syms
 
 
@@ -108,5 +108,7 @@ def lib():
     L.ctt_hip_msm_set_shard_min.argtypes = [sz]
     L.ctt_hip_msm_set_shard_min.restype = None
     L.ctt_hip_subgroup_check.argtypes = [vp, i32, vp, vp, sz, i32]
+    L.ctt_hip_fr_quotient.argtypes = [vp, i32, vp, vp, vp, vp, vp, u32]
+    L.ctt_hip_fr_quotient.restype = i32
     _lib = L
     return L

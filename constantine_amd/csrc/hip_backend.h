@@ -317,6 +317,15 @@ __global__ void __launch_bounds__(EC_BLOCK) k_gen_points(uint64_t seed, uint64_t
   gen_point_body<typename C::F>(G, seed, first, n, out, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+template <class Fr>
+__global__ void __launch_bounds__(EC_BLOCK) k_fr_quotient_inv(FrQuotientArgs<Fr> a) {
+  fr_quotient_inv_body<Fr>(a, blockIdx.x * blockDim.x + threadIdx.x);
+}
+template <class Fr>
+__global__ void __launch_bounds__(256) k_fr_quotient_out(FrQuotientArgs<Fr> a) {
+  fr_quotient_out_body<Fr>(a, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 template <class C>
 __global__ void __launch_bounds__(EC_BLOCK) k_subgroup_check(const Affine<typename C::F>* pts, uint32_t n, uint8_t* ok) {
   subgroup_check_body<C>(pts, n, ok, blockIdx.x * blockDim.x + threadIdx.x);
@@ -456,9 +465,11 @@ struct HipBackend {
   }
   // Stage timing is opt-in (ctt_hip_msm_set_option "timings"): twelve event records per MSM are host time a caller of a
   // small MSM should not pay for a number it does not read.
-  bool timing = false;
+  int timing = 0;   // 0 off, 1 every stage, 2 the accumulate stage only (what a roofline needs; an event record is a barrier
+                    // packet in the queue: twelve per MSM cost a small pipelined MSM 15 % -- 2^16: 0.63 ms per step against 0.55)
+  bool stage_on(int s) const { return timing == 1 || (timing == 2 && (s == ST_ACCUM || s == ST_TOTAL)); }
   void stage_begin(int slot, int s) {
-    if (!timing) return;
+    if (!stage_on(s)) return;
     if (s == ST_TOTAL) {
       for (int i = 0; i < ST_COUNT; i++) ev_used[slot][i] = 0;
       chunk = 0;
@@ -468,7 +479,7 @@ struct HipBackend {
     ev_used[slot][s] |= 1u << ch;
   }
   void stage_end(int slot, int s) {
-    if (!timing) return;
+    if (!stage_on(s)) return;
     const int ch = (s == ST_TOTAL || s == ST_REDUCE) ? 0 : chunk;
     HIP_CHECK(hipEventRecord(ev_end[slot][s][ch], cur()));
   }
@@ -604,6 +615,12 @@ struct CurveOps {
   void (*subgroup_check)(HipBackend* bk, const void* d_points, uint32_t n, void* d_ok);
   // window table over n bases (MsmEngine::prepare_table): records of 2^(c*w) * P_j for every digit window; c = 0 chooses
   void* (*table_prepare)(void* eng, const void* d_points, uint32_t n, int c, int* c_out);
+  // KZG quotient polynomial over the curve's scalar field (msm_bodies.h FrQuotientArgs): d_poly canonical, d_dom Montgomery,
+  // z canonical (host, fr_bytes), d_work >= (n + ceil(n/8)) * fr_bytes; q (device, canonical) and y (host, canonical) out.
+  // Returns 0, or -2 when z is one of the n-th roots of unity (the caller's other formula applies).
+  int (*fr_quotient)(HipBackend* bk, const void* d_poly, const void* d_dom, const void* z_host, uint32_t n, void* d_work,
+                     void* d_q, void* y_host);
+  size_t fr_bytes;
 };
 
 template <class C>
@@ -716,8 +733,45 @@ struct CurveImpl {
                        (const Affine<F>*)d_points, n, (uint8_t*)d_ok);
     HIP_CHECK(hipGetLastError());
   }
+  static int fr_quotient(HipBackend* bk, const void* d_poly, const void* d_dom, const void* z_host, uint32_t n, void* d_work,
+                         void* d_q, void* y_host) {
+    using Fr = typename C::Fr;
+    using HFr = Fp64<typename Fr::Params>;
+    // host side: z -> Montgomery, z^n, (z^n - 1) / n
+    HFr zc, r2, nn = HFr::zero();
+    memcpy(zc.l, z_host, sizeof(zc.l));
+    for (int i = 0; i < HFr::N; i++) r2.l[i] = (uint64_t)Fr::Params::R2[2 * i] | ((uint64_t)Fr::Params::R2[2 * i + 1] << 32);
+    const HFr zm = HFr::mul(zc, r2);
+    HFr zn = HFr::one();
+    for (int b = 31; b >= 0; b--) {
+      zn = HFr::sqr(zn);
+      if ((n >> b) & 1u) zn = HFr::mul(zn, zm);
+    }
+    if (HFr::eq(zn, HFr::one())) return -2;
+    nn.l[0] = n;
+    const HFr scale = HFr::mul(HFr::sub(zn, HFr::one()), HFr::inv(HFr::mul(nn, r2)));
+    FrQuotientArgs<Fr> a;
+    a.poly = (const uint32_t*)d_poly;
+    a.dom = (const uint32_t*)d_dom;
+    memcpy(a.z.l, zm.l, sizeof(a.z.l));
+    memcpy(a.scale.l, scale.l, sizeof(a.scale.l));
+    a.n = n;
+    a.K = 8;
+    a.inv = (uint32_t*)d_work;
+    a.partial = a.inv + (size_t)n * Fr::N;
+    a.q = (uint32_t*)d_q;
+    a.y = a.partial + (size_t)((n + a.K - 1) / a.K) * Fr::N;
+    const uint32_t lanes = (n + a.K - 1) / a.K;
+    hipLaunchKernelGGL(k_fr_quotient_inv<Fr>, dim3((lanes + EC_BLOCK - 1) / EC_BLOCK), dim3(EC_BLOCK), 0, bk->stream, a);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_fr_quotient_out<Fr>, dim3((n + 255) / 256), dim3(256), 0, bk->stream, a);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(y_host, a.y, sizeof(Fr), hipMemcpyDeviceToHost, bk->stream));
+    HIP_CHECK(hipStreamSynchronize(bk->stream));
+    return 0;
+  }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F), subgroup_check, table_prepare};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F), subgroup_check, table_prepare, fr_quotient, sizeof(typename C::Fr)};
     return &o;
   }
 };

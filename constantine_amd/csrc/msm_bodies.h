@@ -35,10 +35,10 @@ static constexpr uint32_t KEY_NONE = 0xffffffffu;
 // chip busy, measured on MI355X (profiles/): what the window-size cost model (msm_pipeline.h choose_window_bits) ranks plans by.
 struct Bls12381G1 { using F = Fp<BLS12_381_Fp>; using FD = FpU<BLS12_381_Fp_U>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 0; static constexpr double ACC_NS = 0.142, RED_NS = 0.26; };
 struct Bls12381G2 { using F = Fp2<Fp<BLS12_381_Fp>>; using FD = Fp2<FpU<BLS12_381_Fp_U>>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 1; static constexpr double ACC_NS = 0.467, RED_NS = 1.1; };
-struct Bn254G1 { using F = Fp<BN254_Fp>; using FD = FpU<BN254_Fp_U>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; static constexpr double ACC_NS = 0.0685, RED_NS = 0.09; };
+struct Bn254G1 { using F = Fp<BN254_Fp>; using FD = FpU<BN254_Fp_U>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; static constexpr double ACC_NS = 0.0685, RED_NS = 0.12; };
 struct Bn254G2 { using F = Fp2<Fp<BN254_Fp>>; using FD = F; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 3; static constexpr double ACC_NS = 0.5, RED_NS = 1.2; };
-struct PallasEc { using F = Fp<Pallas_Fp>; using FD = FpU<Pallas_Fp_U>; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; static constexpr double ACC_NS = 0.056, RED_NS = 0.077; };
-struct VestaEc { using F = Fp<Vesta_Fp>; using FD = FpU<Vesta_Fp_U>; using Fr = Fp<Pallas_Fp>; static constexpr int BITS = 255; static constexpr int ID = 5; static constexpr double ACC_NS = 0.056, RED_NS = 0.077; };
+struct PallasEc { using F = Fp<Pallas_Fp>; using FD = FpU<Pallas_Fp_U>; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; static constexpr double ACC_NS = 0.056, RED_NS = 0.10; };
+struct VestaEc { using F = Fp<Vesta_Fp>; using FD = FpU<Vesta_Fp_U>; using Fr = Fp<Pallas_Fp>; static constexpr int BITS = 255; static constexpr int ID = 5; static constexpr double ACC_NS = 0.056, RED_NS = 0.10; };
 
 // ---------------------------------------------------------------------------------------------
 // Booth signed digits
@@ -658,6 +658,73 @@ CTT_HD void batch_affine_body(const BatchAffineArgs<F>& a, uint32_t lane) {
     }
     a.dst[i] = o;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quotient polynomial of a KZG opening in evaluation form (kzg_prove, commitments/kzg.nim:204-223; getQuotientPoly,
+// math/polynomials/polynomials.nim): for p given by its n evaluations over the (bit-reversed) roots of unity w_i and an
+// opening point z that is NOT one of them,
+//     y = p(z) = (z^n - 1)/n * sum_i p_i w_i / (z - w_i)          (barycentric)       q_i = (p_i - y) / (w_i - z) .
+// The n inversions are one Montgomery-trick run and ONE inversion (modinv.h) per lane over K consecutive elements.  Rounds 1-2
+// did this in host Python integers: 4 ms next to a 0.36 ms MSM.  poly: canonical scalars as the MSM takes them; dom, z, inv:
+// Montgomery residues; partial / q / y: canonical (a Montgomery product of a canonical and a Montgomery factor is canonical).
+// ---------------------------------------------------------------------------------------------
+template <class Fr>
+struct FrQuotientArgs {
+  const uint32_t* poly;   // [n][Fr::N]  p_i, canonical
+  const uint32_t* dom;    // [n][Fr::N]  w_i, Montgomery
+  Fr z;                   // Montgomery
+  Fr scale;               // (z^n - 1) / n, Montgomery
+  uint32_t n, K;          // elements; elements per lane of the first pass
+  uint32_t* inv;          // [n][Fr::N]  1 / (z - w_i), Montgomery                      (pass 1 -> pass 2)
+  uint32_t* partial;      // [ceil(n/K)][Fr::N]  per-lane sums of p_i w_i / (z - w_i), canonical
+  uint32_t* q;            // [n][Fr::N]  out: quotient evaluations, canonical
+  uint32_t* y;            // [Fr::N]     out: p(z), canonical
+};
+template <class Fr>
+CTT_HD Fr fr_load(const uint32_t* a, uint64_t i) {
+  Fr r;
+#pragma unroll
+  for (int k = 0; k < Fr::N; k++) r.l[k] = a[i * Fr::N + k];
+  return r;
+}
+template <class Fr>
+CTT_HD void fr_store(uint32_t* a, uint64_t i, const Fr& v) {
+#pragma unroll
+  for (int k = 0; k < Fr::N; k++) a[i * Fr::N + k] = v.l[k];
+}
+// pass 1, lane `lane`: inv_i for its K elements and the lane's share of the barycentric sum
+template <class Fr>
+CTT_HD void fr_quotient_inv_body(const FrQuotientArgs<Fr>& a, uint32_t lane) {
+  const uint64_t i0 = (uint64_t)lane * a.K;
+  if (i0 >= a.n) return;
+  const uint64_t i1 = i0 + a.K < a.n ? i0 + a.K : a.n;
+  Fr run = Fr::one();
+  for (uint64_t i = i0; i < i1; i++) {               // prefix products parked in inv[]
+    fr_store<Fr>(a.inv, i, run);
+    run = Fr::mul(run, Fr::sub(a.z, fr_load<Fr>(a.dom, i)));
+  }
+  Fr iv = Fr::inv(run);
+  Fr sum = Fr::zero();
+  for (uint64_t i = i1; i-- > i0;) {
+    const Fr w = fr_load<Fr>(a.dom, i);
+    const Fr di = Fr::mul(iv, fr_load<Fr>(a.inv, i));  // 1 / (z - w_i)
+    iv = Fr::mul(iv, Fr::sub(a.z, w));
+    fr_store<Fr>(a.inv, i, di);
+    sum = Fr::add(sum, Fr::mul(fr_load<Fr>(a.poly, i), Fr::mul(w, di)));   // canonical p_i times Montgomery w_i / (z - w_i)
+  }
+  fr_store<Fr>(a.partial, lane, sum);
+}
+// pass 2, element i: y from the lane sums (every lane computes the same y), q_i = (y - p_i) / (z - w_i)
+template <class Fr>
+CTT_HD void fr_quotient_out_body(const FrQuotientArgs<Fr>& a, uint32_t i) {
+  if (i >= a.n) return;
+  const uint32_t lanes = (a.n + a.K - 1) / a.K;
+  Fr s = Fr::zero();
+  for (uint32_t l = 0; l < lanes; l++) s = Fr::add(s, fr_load<Fr>(a.partial, l));
+  const Fr y = Fr::mul(s, a.scale);                   // canonical
+  if (i == 0) fr_store<Fr>(a.y, 0, y);
+  fr_store<Fr>(a.q, i, Fr::mul(Fr::sub(y, fr_load<Fr>(a.poly, i)), fr_load<Fr>(a.inv, i)));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -639,7 +639,11 @@ struct MsmEngine {
     // copy: ~0.15 ms of latency, a handful of waves) run BESIDE this accumulation when the accumulate grid leaves wave slots
     // free (accumulate_pairs); for small MSMs it pays to leave them free on purpose -- a sixth of the lanes, K grows by a
     // fifth (measured, BLS12-381 G1 2^17, ms per MSM with two in flight: 0.69 with 17 % of the slots free, 0.80 with 5 %).
-    if (slots[sl ^ 1].busy && n <= (1u << 17) && opt.K <= 0) po.lanes = (uint32_t)((uint64_t)opt.lanes * 27u / 32u);
+    // (the window size is chosen for the whole chip first: fewer lanes must only lengthen K)
+    if (slots[sl ^ 1].busy && n <= (1u << 17) && opt.K <= 0 && table_c <= 0) {
+      if (po.c <= 0) po.c = choose_window_bits(n, C::BITS, opt.lanes, opt.acc_ns, opt.red_ns);
+      po.lanes = (uint32_t)((uint64_t)opt.lanes * 27u / 32u);
+    }
     const MsmPlan p = table_c > 0 ? make_table_plan(n, C::BITS, table_c, table_n, po) : make_plan(n, C::BITS, po);
     slots[sl].plan = p;
     last_plan = p;
@@ -688,16 +692,25 @@ struct MsmEngine {
     const int sl = claim_slot(n);
     if (sl < 0 || n == 0) return sl;
     const uint32_t nch = host_chunks(n, want_chunks);
-    // Growing slices: only the first slice's upload is exposed, and slice i+1 may be as much larger than slice i as the
-    // GPU takes longer over a pair than the PCIe link does (accumulate + sort ~3.3 ms against 2.4 ms of copy for 2^20
-    // BLS12-381 pairs) -- weights 1, 1.4, 1.96, ...; every slice a multiple of 64 pairs except the last.
+    // Slice sizes.  The GPU needs gpu_ns per pair (windows x the curve's accumulate time + sort), the pageable copy copy_ns
+    // (56 GB/s measured, profiles/h2d_overlap_r02.jsonl).  GPU-bound (BLS12-381: 2.5 against 2.3 ns; G2): only the first
+    // slice's upload is exposed, and slice i+1 may be as much larger than slice i as the GPU takes longer over a pair than the
+    // link does -- weights 1, g, g^2, ... with g <= 1.4.  Copy-bound (the 254/255-bit curves: 1.2 against 1.7 ns -- the
+    // Halo2-ZAL configuration): the whole copy is on the critical path whatever the slicing and what is exposed is the LAST
+    // slice's GPU work, so the slices shrink instead (round 2 grew them for every curve: 39 % of a BN254 2^22 call's pairs
+    // were accumulated after the last byte had arrived, 10.4 ms per call against 7.2 ms of copy).  Every slice a multiple of 64
+    // pairs except the last.
+    const double gpu_ns = (double)((C::BITS + 16) / 16) * C::ACC_NS * 1.12, copy_ns = (double)(32 + sizeof(Affine<F>)) / 56.0;
+    double growth = gpu_ns / copy_ns;
+    if (growth > 1.4) growth = 1.4;
+    if (growth < 0.7) growth = 0.7;
     std::vector<uint32_t> bound(nch + 1, 0);
     {
       double wsum = 0, w = 1;
-      for (uint32_t i = 0; i < nch; i++, w *= 1.4) wsum += w;
+      for (uint32_t i = 0; i < nch; i++, w *= growth) wsum += w;
       double acc = 0;
       w = 1;
-      for (uint32_t i = 0; i + 1 < nch; i++, w *= 1.4) {
+      for (uint32_t i = 0; i + 1 < nch; i++, w *= growth) {
         acc += w;
         uint64_t b = (uint64_t)((double)n * acc / wsum);
         b &= ~63ull;

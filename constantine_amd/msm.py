@@ -168,8 +168,9 @@ class DeviceMsm:
             raise RuntimeError("ctt_hip_batch_affine failed")
 
     def enable_timings(self, on=True):
-        """Record the per-stage HIP events that last_timings() reads (off by default: they are host time per MSM)."""
-        self.set_option("timings", 1 if on else 0)
+        """Record the per-stage HIP events that last_timings() reads (off by default: they are host time per MSM and barrier
+        packets in the queue).  on = 2: the accumulate stage and the total only (what a roofline needs)."""
+        self.set_option("timings", int(on))
 
     def last_timings(self):
         ms = np.zeros(6, dtype=np.float32)

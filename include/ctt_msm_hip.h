@@ -144,8 +144,8 @@ ctt_hip_msm_ctx* ctt_hip_msm_ctx_create(int device);
 void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
 /* key: "c" window bits, "K" sorted entries per accumulate lane, "S" scalars per sort-partition workgroup, "chunks" slices a
  * host-pointer call is uploaded in (the upload of slice i+1 runs underneath the accumulation of slice i),
- * "host_window_sums" where the Horner over a window's bit sums runs (0 automatic: on the device unless the caller keeps MSMs
- * in flight, 1 host, 2 device), "timings" 1 = record the stage events ctt_hip_msm_last_timings reads.  value 0 = automatic /
+ * "horner_bits" bits per group of the bit Horner the device runs per window (0 = 4; the host joins the groups),
+ * "host_window_sums" (legacy spelling: 1 = groups of one bit, 2 = one group per window), "timings" 1 = record the stage events ctt_hip_msm_last_timings reads.  value 0 = automatic /
  * off.  Returns 0, or -1 for an unknown key. */
 int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
 /* r (HOST memory, `out_kind` layout) = sum coefs[i] * points[i]; d_coefs / d_points are DEVICE pointers
@@ -225,6 +225,14 @@ int ctt_hip_batch_affine(ctt_hip_msm_ctx* ctx, int curve, int src_kind, void* ds
  * on deserialised points (eth_evm_bls12381_g1msm / g2msm, ethereum_evm_precompiles.nim:894-975; KZG commitments), for all n
  * points in one launch.  points: affine, host (points_on_device = 0) or device memory; ok: n bytes of host memory. */
 int ctt_hip_subgroup_check(ctt_hip_msm_ctx* ctx, int curve, uint8_t* ok, const void* points, size_t n, int points_on_device);
+/* Quotient polynomial of a KZG opening over the scalar field of `curve`, in evaluation form: the Fr-side work of kzg_prove
+ * (constantine/commitments/kzg.nim:204-223 -> getQuotientPoly).  d_poly: n canonical scalars (the MSM's coefficient format),
+ * d_domain: the n roots of unity as Montgomery residues, both in DEVICE memory; z: the opening point, canonical, host.  Writes
+ * q_i = (p_i - y) / (w_i - z), canonical, to d_q (device: the coefficients of the proof's MSM) and y = p(z), canonical, to y
+ * (host).  Blocking.  Returns 0; -2 when z is one of the roots of unity (the reference's other branch, left to the caller);
+ * -1 for bad arguments or when device memory runs out. */
+int ctt_hip_fr_quotient(ctt_hip_msm_ctx* ctx, int curve, void* d_q, void* y, const void* d_poly, const void* d_domain,
+                        const void* z, uint32_t n);
 /* the engine's hipStream_t */
 void* ctt_hip_msm_stream(ctt_hip_msm_ctx* ctx);
 

@@ -22,10 +22,14 @@
 //   window-level + msm-level (point sharding) threads  constantine/math/elliptic/ec_multi_scalar_mul_parallel.nim:148-208,386-431,519-553
 //   balanced chunking ................................ constantine/threadpool/partitioners.nim:44-77
 //
-// Deliberate simplification (documented in DESIGN.md): buckets are always Jacobian
-// (the reference switches to batched-affine buckets for c >= 9, scheduler.nim:414-553) and no
-// endomorphism pre-split is applied (ec_multi_scalar_mul.nim:398-432).  Both only change the
-// operation count, never the group element returned.
+//   batched-affine bucket accumulation for c >= 9 ... constantine/math/elliptic/ec_multi_scalar_mul_scheduler.nim:266-553 (scheduler,
+//                                                      collision queue, sparseVectorAddition), additions ec_shortweierstrass_batch_ops.nim:424-455,
+//                                                      dispatch ec_multi_scalar_mul.nim:478-490 (round 3: rounds 1-2 kept Jacobian buckets throughout,
+//                                                      which understated the CPU baseline)
+//
+// Deliberate simplification (documented in DESIGN.md): no endomorphism pre-split is applied
+// (ec_multi_scalar_mul.nim:398-432) and the field inversion is a^(p-2), not the reference's division steps.
+// Both only change the operation count, never the group element returned.
 //
 // Build: g++ -O3 -march=native -shared -fPIC -pthread oracle/msm_ref.cpp -o oracle/libmsm_ref.so
 
@@ -384,15 +388,145 @@ static Jac<F> window_sum(const Scalar* coefs, const Aff<F>* pts, size_t n, int w
   return r;
 }
 
+// ------------------------------------------------------------------------------------------
+// Affine buckets with a scheduler (the reference's choice for c >= 9, ec_multi_scalar_mul.nim:478-490): points are queued
+// per bucket, at most one pending addition per bucket in a batch (a second one waits in the collision queue), and a full
+// queue is flushed as ONE vector of affine additions sharing a single inversion (sparseVectorAddition): 6 field
+// multiplications per addition + a share of the inversion, against 11 for a Jacobian mixed addition.
+// ------------------------------------------------------------------------------------------
+template <class F>
+struct AffineBuckets {
+  struct Sched { uint32_t bucket; uint32_t point; bool neg; };
+  std::vector<Aff<F>> pt;          // bucket sums (valid where full[b])
+  std::vector<uint8_t> full, busy;  // bucket holds a point; bucket has an addition pending in the queue
+  std::vector<Sched> queue, collisions;
+  std::vector<F> num, den, pre;    // per queued addition: lambda numerator / denominator, running products
+  size_t qlen;
+  const Aff<F>* points = nullptr;
+
+  explicit AffineBuckets(int c) {
+    const size_t B = (size_t)1 << (c - 1);
+    pt.resize(B);
+    full.assign(B, 0);
+    busy.assign(B, 0);
+    const long ql = 4L * c * c - 16L * c - 128;   // deriveSchedulerConstants, scheduler.nim:266-269
+    qlen = (size_t)(ql > 32 ? ql : 32);
+    queue.reserve(qlen);
+    collisions.reserve(qlen);
+    num.resize(qlen);
+    den.resize(qlen);
+    pre.resize(qlen);
+  }
+  void reset(const Aff<F>* p) {
+    points = p;
+    std::fill(full.begin(), full.end(), 0);
+    std::fill(busy.begin(), busy.end(), 0);
+    queue.clear();
+    collisions.clear();
+  }
+  // one vector of affine additions bucket[b] += +-P (affine chord-and-tangent with Montgomery's simultaneous inversion;
+  // P == bucket doubles, P == -bucket empties the bucket: the special cases of scheduler.nim:414-553)
+  void flush() {
+    const size_t m = queue.size();
+    F run = F::one();
+    for (size_t i = 0; i < m; i++) {
+      const Sched& q = queue[i];
+      const Aff<F>& b = pt[q.bucket];
+      const Aff<F>& p = points[q.point];
+      const F py = q.neg ? F::neg(p.y) : p.y;
+      F dx = F::sub(p.x, b.x);
+      if (dx.is_zero()) {
+        if (py == b.y && !py.is_zero()) {             // doubling: lambda = 3 x^2 / 2 y
+          F xx = F::sqr(b.x);
+          num[i] = F::add(F::dbl(xx), xx);
+          den[i] = F::dbl(b.y);
+        } else {                                      // opposite points (or a point of order two): the sum is the neutral element
+          num[i] = F::zero();
+          den[i] = F::zero();
+        }
+      } else {
+        num[i] = F::sub(py, b.y);
+        den[i] = dx;
+      }
+      pre[i] = run;
+      if (!den[i].is_zero()) run = F::mul(run, den[i]);
+    }
+    F inv = F::inv(run);
+    for (size_t i = m; i-- > 0;) {
+      const Sched& q = queue[i];
+      busy[q.bucket] = 0;
+      if (den[i].is_zero()) {
+        full[q.bucket] = 0;
+        continue;
+      }
+      const F dinv = F::mul(inv, pre[i]);
+      inv = F::mul(inv, den[i]);
+      const F lam = F::mul(num[i], dinv);
+      Aff<F>& b = pt[q.bucket];
+      const Aff<F>& p = points[q.point];
+      const F x3 = F::sub(F::sub(F::sqr(lam), b.x), p.x);
+      const F y3 = F::sub(F::mul(lam, F::sub(b.x, x3)), b.y);
+      b.x = x3;
+      b.y = y3;
+    }
+    queue.clear();
+    // the collisions of this batch are scheduled again (rescheduleCollisions)
+    std::vector<Sched> again;
+    again.swap(collisions);
+    for (const Sched& q : again) schedule(q);
+  }
+  void schedule(const Sched& q) {
+    const Aff<F>& p = points[q.point];
+    if (p.is_inf()) return;
+    if (!full[q.bucket] && !busy[q.bucket]) {          // empty bucket: the point moves in, no addition
+      pt[q.bucket] = {p.x, q.neg ? F::neg(p.y) : p.y};
+      full[q.bucket] = 1;
+      return;
+    }
+    if (busy[q.bucket]) {                             // a second addition to the same bucket must wait for the first
+      collisions.push_back(q);
+      if (collisions.size() >= qlen) flush();
+      return;
+    }
+    busy[q.bucket] = 1;
+    queue.push_back(q);
+    if (queue.size() >= qlen) flush();
+  }
+  void finish() { while (!queue.empty() || !collisions.empty()) flush(); }
+};
+
+// miniMSM_affine, ec_multi_scalar_mul.nim:329-345: schedAccumulate, then bucketReduce over the affine buckets
+template <class F>
+static Jac<F> window_sum_affine(const Scalar* coefs, const Aff<F>* pts, size_t n, int w, int c, AffineBuckets<F>& bk) {
+  const size_t B = (size_t)1 << (c - 1);
+  bk.reset(pts);
+  for (size_t j = 0; j < n; j++) {
+    uint32_t val; bool neg;
+    booth_digit(coefs[j], w, c, val, neg);
+    if (val == 0) continue;
+    bk.schedule({val - 1, (uint32_t)j, neg});
+  }
+  bk.finish();
+  Jac<F> acc = Jac<F>::inf(), r = Jac<F>::inf();
+  for (size_t k = B; k-- > 0;) {
+    if (bk.full[k]) acc = Jac<F>::madd(acc, bk.pt[k], false);
+    r = Jac<F>::add(r, acc);
+  }
+  return r;
+}
+static constexpr int AFFINE_BUCKETS_FROM_C = 9;   // ec_multi_scalar_mul.nim:478-490
+
 // msmImpl_vartime, ec_multi_scalar_mul.nim:256-296 (serial: windows top -> bottom, one bucket array)
 template <class F>
 static Jac<F> msm_serial(const Scalar* coefs, const Aff<F>* pts, size_t n, int bits, int c) {
   const int W = bits / c + 1;
-  std::vector<Jac<F>> buckets((size_t)1 << (c - 1));
+  const bool affine = c >= AFFINE_BUCKETS_FROM_C && n < (1ull << 32);
+  std::vector<Jac<F>> buckets(affine ? 0 : (size_t)1 << (c - 1));
+  AffineBuckets<F> ab(affine ? c : 2);
   Jac<F> r = Jac<F>::inf();
   for (int w = W - 1; w >= 0; w--) {
     for (int k = 0; k < c; k++) r = Jac<F>::dbl(r);
-    r = Jac<F>::add(r, window_sum<F>(coefs, pts, n, w, c, buckets.data()));
+    r = Jac<F>::add(r, affine ? window_sum_affine<F>(coefs, pts, n, w, c, ab) : window_sum<F>(coefs, pts, n, w, c, buckets.data()));
   }
   return r;
 }
@@ -413,14 +547,17 @@ static Jac<F> msm_parallel(const Scalar* coefs, const Aff<F>* pts, size_t n, int
   const int ntasks = msmpar * W;
   std::vector<Jac<F>> sums(ntasks);
   std::atomic<int> next(0);
+  const bool affine = c >= AFFINE_BUCKETS_FROM_C && n < (1ull << 32);
   auto worker = [&]() {
-    std::vector<Jac<F>> buckets((size_t)1 << (c - 1));
+    std::vector<Jac<F>> buckets(affine ? 0 : (size_t)1 << (c - 1));
+    AffineBuckets<F> ab(affine ? c : 2);
     for (;;) {
       int t = next.fetch_add(1);
       if (t >= ntasks) break;
       int chunk = t / W, w = W - 1 - (t % W);
-      sums[chunk * W + w] = window_sum<F>(coefs + start[chunk], pts + start[chunk],
-                                          start[chunk + 1] - start[chunk], w, c, buckets.data());
+      const size_t cn = start[chunk + 1] - start[chunk];
+      sums[chunk * W + w] = affine ? window_sum_affine<F>(coefs + start[chunk], pts + start[chunk], cn, w, c, ab)
+                                   : window_sum<F>(coefs + start[chunk], pts + start[chunk], cn, w, c, buckets.data());
     }
   };
   std::vector<std::thread> th;

@@ -63,6 +63,21 @@ def msm_slots(curve, coefs, points):
     return out, refused
 
 
+def fr_quotient(curve, poly, dom_mont, z_mont, scale_mont, K=8):
+    """The per-lane bodies of ctt_hip_fr_quotient on the CPU: (q canonical (n, 32), y canonical (32,))."""
+    poly = np.ascontiguousarray(poly, dtype=np.uint8)
+    dom_mont = np.ascontiguousarray(dom_mont, dtype=np.uint8)
+    n = poly.shape[0]
+    q = np.zeros((n, 32), dtype=np.uint8)
+    y = np.zeros(32, dtype=np.uint8)
+    L = lib()
+    L.emu_fr_quotient.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    zm = np.ascontiguousarray(z_mont, dtype=np.uint8)
+    sm = np.ascontiguousarray(scale_mont, dtype=np.uint8)
+    assert L.emu_fr_quotient(CURVE_ID[curve], _p(poly), _p(dom_mont), _p(zm), _p(sm), n, K, _p(q), _p(y)) == 0
+    return q, y
+
+
 def msm_host(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, chunks=0):
     """The host-pointer form of the engine (MsmEngine::submit_host): inputs uploaded in slices, one bucket set per slice.
     Returns (result, slices used)."""

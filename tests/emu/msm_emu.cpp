@@ -169,6 +169,9 @@ struct EmuOps {
   // ticket order: submit A, then two complete MSMs B and C while A is outstanding, then finish A; r3 = 3 affine results;
   // returns the number of submits that were refused (0 expected)
   int (*msm_slots)(void* r3, const void* coefs, const void* points, size_t n);
+  // KZG quotient over the curve's scalar field (msm_bodies.h FrQuotientArgs): poly canonical, dom / z / scale Montgomery
+  void (*fr_quotient)(const void* poly, const void* dom, const void* z_mont, const void* scale_mont, uint32_t n, uint32_t K, void* q,
+                      void* y);
 };
 
 #ifdef EMU_CURVE
@@ -310,8 +313,27 @@ struct EmuCurve {
     write_result<HF>(r3, eng.finish(a), OUT_AFF);
     return refused;
   }
+  static void fr_quotient(const void* poly, const void* dom, const void* z_mont, const void* scale_mont, uint32_t n, uint32_t K,
+                          void* q, void* y) {
+    using Fr = typename C::Fr;
+    const uint32_t lanes = (n + K - 1) / K;
+    std::vector<uint32_t> inv((size_t)n * Fr::N), partial((size_t)lanes * Fr::N);
+    FrQuotientArgs<Fr> a;
+    a.poly = (const uint32_t*)poly;
+    a.dom = (const uint32_t*)dom;
+    memcpy(a.z.l, z_mont, sizeof(a.z.l));
+    memcpy(a.scale.l, scale_mont, sizeof(a.scale.l));
+    a.n = n;
+    a.K = K;
+    a.inv = inv.data();
+    a.partial = partial.data();
+    a.q = (uint32_t*)q;
+    a.y = (uint32_t*)y;
+    for (uint32_t l = 0; l < lanes; l++) fr_quotient_inv_body<Fr>(a, l);
+    for (uint32_t i = 0; i < n; i++) fr_quotient_out_body<Fr>(a, i);
+  }
   static const EmuOps* ops() {
-    static const EmuOps o = {msm, msm_host, msm_table, gen, fop, fop_dev, dev_info, sum_reduce, batch_affine, msm_slots};
+    static const EmuOps o = {msm, msm_host, msm_table, gen, fop, fop_dev, dev_info, sum_reduce, batch_affine, msm_slots, fr_quotient};
     return &o;
   }
 };
@@ -407,6 +429,13 @@ int emu_batch_affine(int curve, int src_kind, void* dst, const void* src, size_t
 int emu_msm_slots(int curve, void* r3, const void* coefs, const void* points, size_t n) {
   const EmuOps* o = ops_of(curve);
   return o ? o->msm_slots(r3, coefs, points, n) : -1;
+}
+int emu_fr_quotient(int curve, const void* poly, const void* dom, const void* z_mont, const void* scale_mont, uint32_t n, uint32_t K,
+                    void* q, void* y) {
+  const EmuOps* o = ops_of(curve);
+  if (!o) return -1;
+  o->fr_quotient(poly, dom, z_mont, scale_mont, n, K, q, y);
+  return 0;
 }
 int emu_dev_field_info(int curve, int* lb, int* nl) {
   const EmuOps* o = ops_of(curve);

@@ -158,3 +158,57 @@ def test_compute_kzg_proof_vectors_on_gpu():
                 assert kzg.compute_blob_kzg_proof(ctx, blob, com) == res, case
     finally:
         ctx.delete()
+
+
+def test_quotient_polynomial_bodies_match_the_host_formula():
+    """ctt_hip_fr_quotient's per-lane bodies (msm_bodies.h fr_quotient_*_body, run here by tests/emu) against the host formula
+    quotient_polynomial: barycentric y = p(z) and q_i = (p_i - y)/(w_i - z) over the bit-reversed 4096-point domain, for several
+    lane spans (one Montgomery-trick run and one inversion per lane)."""
+    import random
+
+    from constantine_amd import kzg
+    from tests.emu import emu
+    r = kzg._R
+    n = kzg.FIELD_ELEMENTS_PER_BLOB
+    rng = random.Random(44)
+    dom = kzg._domain_brp()
+    R = 1 << 256
+    dom_m = np.frombuffer(b"".join((w * R % r).to_bytes(32, "little") for w in dom), dtype=np.uint8).reshape(n, 32)
+    for K in (8, 5, 64):
+        poly = [rng.randrange(r) for _ in range(n)]
+        poly[3] = 0
+        poly[7] = r - 1
+        z = rng.randrange(r)
+        assert pow(z, n, r) != 1
+        want_q, want_y = kzg.quotient_polynomial(poly, z)
+        poly_le = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in poly), dtype=np.uint8).reshape(n, 32)
+        scale = (pow(z, n, r) - 1) * pow(n, -1, r) % r
+        q, y = emu.fr_quotient("bls12_381_g1", poly_le, dom_m, np.frombuffer((z * R % r).to_bytes(32, "little"), dtype=np.uint8),
+                               np.frombuffer((scale * R % r).to_bytes(32, "little"), dtype=np.uint8), K=K)
+        assert int.from_bytes(bytes(y), "little") == want_y
+        assert [int.from_bytes(bytes(row), "little") for row in q] == want_q
+
+
+@pytest.mark.gpu
+def test_quotient_polynomial_on_device_matches_the_host_formula():
+    """The device path of the proofs (ctt_hip_fr_quotient) against quotient_polynomial, and the branch it leaves to the host
+    (z a root of unity: -2)."""
+    import random
+
+    import os
+
+    from constantine_amd import kzg
+    ctx = kzg.EthereumKZGContext(open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read())
+    r = kzg._R
+    n = kzg.FIELD_ELEMENTS_PER_BLOB
+    rng = random.Random(45)
+    for _ in range(3):
+        poly = [rng.randrange(r) for _ in range(n)]
+        z = rng.randrange(r)
+        want_q, want_y = kzg.quotient_polynomial(poly, z)
+        poly_le = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in poly), dtype=np.uint8).reshape(n, 32)
+        d_q, y = kzg.quotient_polynomial_device(ctx, poly_le, z)
+        assert y == want_y
+        assert [int.from_bytes(bytes(row), "little") for row in d_q.cpu().numpy()] == want_q
+    assert kzg.quotient_polynomial_device(ctx, poly_le, kzg._domain_brp()[5]) is None
+    ctx.delete()

@@ -60,16 +60,25 @@ def main():
                 eng.set_option(k, v)
             eng.enable_timings(False)
 
+            host = {"submit": 0.0, "finish": 0.0, "n": 0}
+
             def run(k):
                 r = None
                 pend = eng.submit(curve, d_scal, d_points, n)
                 for i in range(k):
+                    ta = time.perf_counter()
                     nxt = eng.submit(curve, d_scal, d_points, n) if i + 1 < k else None
+                    tb = time.perf_counter()
                     r = eng.finish(pend, coord="aff")
+                    tc = time.perf_counter()
+                    host["submit"] += tb - ta
+                    host["finish"] += tc - tb
+                    host["n"] += 1
                     pend = nxt
                 return r
             run(3)
             eng.sync()
+            host.update(submit=0.0, finish=0.0, n=0)
             t0 = time.perf_counter()
             r = run(steps)
             eng.sync()
@@ -88,6 +97,8 @@ def main():
             print(json.dumps({"curve": curve, "log2n": log2n, "opt": dict(zip(keys, combo)), "plan": eng.last_plan(),
                               "ms_per_step": round(ms, 4), "Mpairs_s": round(n / ms / 1e3, 1),
                               "blocking_ms": round(statistics.median(lat[2:]), 4), "same": bytes(r) == ref,
+                              "host_ms_in_submit": round(host["submit"] / max(1, host["n"]) * 1e3, 4),
+                              "host_ms_in_finish": round(host["finish"] / max(1, host["n"]) * 1e3, 4),
                               "stage_ms_blocking": {k: round(v, 3) for k, v in st.items()}}), flush=True)
         for k in keys:
             eng.set_option(k, 0)
