@@ -363,7 +363,8 @@ def main():
             out["cpu_baseline"] = {
                 "value": m / cpu_dt, "unit": "points/s", "cores": cores, "kind": "port",
                 "sample": f"first 2^{int(np.log2(m))} pairs of the same workload, oracle/msm_ref.cpp "
-                          f"(restatement of Constantine's Pippenger, not Constantine), c={c_used}, median of 3 runs "
+                          f"(restatement of Constantine's Pippenger with its batched-affine buckets, not Constantine: no endomorphism, "
+                          f"no assembly), c={c_used}, median of 3 runs "
                           f"({', '.join(f'{r:.2f}' for r in runs)} s wall), "
                           f"{cores} threads on a {budget}-CPU cgroup quota ({os.cpu_count()} logical CPUs visible, {cpu_model()}); {flags}",
             }

@@ -682,7 +682,9 @@ struct MsmEngine {
     // 2^18: 2.31 / 2.79 (2 slices: 2.35), 2^20: 6.37 / 5.05, 2^22: 22.8 / 15.4): only the first slice's upload is exposed,
     // every extra slice costs one more sort launch sequence and one more addition per bucket.
     // An explicit request is honoured.
-    uint32_t cch = want > 0 ? (uint32_t)want : (n >= (3u << 18) ? 4u : n >= (3u << 17) ? 2u : 1u);
+    // Round 3 (no host wait between the slices any more, profiles/hostptr_r03.txt): 2^18 1.93 (2 slices) / 2.03 (3), 2^20 6.08 (1) /
+    // 5.00 (2) / 4.49 (3) / 4.58 (4), 2^22 22.3 / 17.2 / 15.5 / 14.4.
+    uint32_t cch = want > 0 ? (uint32_t)want : (n >= (1u << 21) ? 4u : n >= (3u << 18) ? 3u : n >= (3u << 17) ? 2u : 1u);
     if (cch > 8) cch = 8;
     if (cch > n) cch = n;
     return cch < 1 ? 1 : cch;
