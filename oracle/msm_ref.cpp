@@ -514,19 +514,22 @@ static Jac<F> window_sum_affine(const Scalar* coefs, const Aff<F>* pts, size_t n
   }
   return r;
 }
-static constexpr int AFFINE_BUCKETS_FROM_C = 9;   // ec_multi_scalar_mul.nim:478-490
+static const int AFFINE_BUCKETS_FROM_C = getenv("ORACLE_JACOBIAN_BUCKETS") ? 99 : 9;   // ec_multi_scalar_mul.nim:478-490 ($ORACLE_JACOBIAN_BUCKETS: rounds 1-2's form, for A/B)
 
 // msmImpl_vartime, ec_multi_scalar_mul.nim:256-296 (serial: windows top -> bottom, one bucket array)
 template <class F>
 static Jac<F> msm_serial(const Scalar* coefs, const Aff<F>* pts, size_t n, int bits, int c) {
   const int W = bits / c + 1;
   const bool affine = c >= AFFINE_BUCKETS_FROM_C && n < (1ull << 32);
-  std::vector<Jac<F>> buckets(affine ? 0 : (size_t)1 << (c - 1));
+  std::vector<Jac<F>> buckets((size_t)1 << (c - 1));
   AffineBuckets<F> ab(affine ? c : 2);
   Jac<F> r = Jac<F>::inf();
   for (int w = W - 1; w >= 0; w--) {
     for (int k = 0; k < c; k++) r = Jac<F>::dbl(r);
-    r = Jac<F>::add(r, affine ? window_sum_affine<F>(coefs, pts, n, w, c, ab) : window_sum<F>(coefs, pts, n, w, c, buckets.data()));
+    // the top window has fewer bits, hence few buckets and a collision per point in the scheduler: the reference keeps the
+    // non-affine accumulation for it (ec_multi_scalar_mul.nim:364-372: kTopWindow -> bucketAccumReduce)
+    const bool aff_w = affine && w != W - 1;
+    r = Jac<F>::add(r, aff_w ? window_sum_affine<F>(coefs, pts, n, w, c, ab) : window_sum<F>(coefs, pts, n, w, c, buckets.data()));
   }
   return r;
 }
@@ -549,15 +552,16 @@ static Jac<F> msm_parallel(const Scalar* coefs, const Aff<F>* pts, size_t n, int
   std::atomic<int> next(0);
   const bool affine = c >= AFFINE_BUCKETS_FROM_C && n < (1ull << 32);
   auto worker = [&]() {
-    std::vector<Jac<F>> buckets(affine ? 0 : (size_t)1 << (c - 1));
+    std::vector<Jac<F>> buckets((size_t)1 << (c - 1));
     AffineBuckets<F> ab(affine ? c : 2);
     for (;;) {
       int t = next.fetch_add(1);
       if (t >= ntasks) break;
       int chunk = t / W, w = W - 1 - (t % W);
       const size_t cn = start[chunk + 1] - start[chunk];
-      sums[chunk * W + w] = affine ? window_sum_affine<F>(coefs + start[chunk], pts + start[chunk], cn, w, c, ab)
-                                   : window_sum<F>(coefs + start[chunk], pts + start[chunk], cn, w, c, buckets.data());
+      // (the top window keeps the Jacobian accumulation, as in the reference: few buckets, a collision per point)
+      sums[chunk * W + w] = (affine && w != W - 1) ? window_sum_affine<F>(coefs + start[chunk], pts + start[chunk], cn, w, c, ab)
+                                                   : window_sum<F>(coefs + start[chunk], pts + start[chunk], cn, w, c, buckets.data());
     }
   };
   std::vector<std::thread> th;
