@@ -72,9 +72,46 @@ __global__ void __launch_bounds__(CONVERT_BLOCK) k_convert_points(const Affine<F
 #endif
 // an XYZZ accumulator over Fp2 (448 bytes) plus a point and the temporaries of the addition does not fit two waves per SIMD
 // (parking ZZ, ZZZ in LDS to get there was measured and rejected: DESIGN.md section 5)
+// The gather of the accumulate loop, device form (msm_bodies.h GatherDirect for the contract): request() has the record of
+// the NEXT entry written into LDS by global_load_lds_dwordx4 while the current addition runs -- the data never waits in
+// registers (a register-staged request costs 29 / 57 VGPRs: 242 of 256 for BLS12-381 G1, spills for the 9-limb fields at four
+// waves per SIMD and for G2 at 512).  One workgroup = one wave: chunk j of lane l lies at stage[j][l], which is where the
+// instruction puts it (LDS address = M0 + lane * 16).  collect() waits for everything the lane has in flight (vmcnt counts the
+// LDS-bound loads too) and reads the chunks back.
+template <class F>
+struct GatherLds {
+  static constexpr uint32_t NCH = gather_chunks<F>();
+  static_assert(F::UNSAT, "records in the converted layout only");
+  uint4 (*stage)[ACCUM_BLOCK];
+  __device__ void request(const char* rec) {
+    // the previous record has been read out of the staging lines (collect's ds_reads have returned) before they are overwritten
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (uint32_t j = 0; j < NCH; j++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec + 16u * j),
+                                       (__attribute__((address_space(3))) void*)&stage[j][0], 16, 0, 0);
+  }
+  __device__ void collect(Affine<F>& pt, bool& qinf) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    union {
+      uint4 q[NCH];
+      uint32_t w[NCH * 4u];
+    } r;
+#pragma unroll
+    for (uint32_t j = 0; j < NCH; j++) r.q[j] = stage[j][threadIdx.x];
+    __builtin_memcpy(&pt, r.w, sizeof(Affine<F>));
+    qinf = r.w[gather_flag_offset<F>() / 4u] != 0u;
+  }
+};
 template <class F>
 __global__ void __launch_bounds__(ACCUM_BLOCK, (sizeof(XYZZ<F>) > 256 ? 1 : CTT_ACCUM_WAVES)) k_accum(AccumArgs<F> a) {
-  accum_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+  if constexpr (F::UNSAT && !IsFp2<F>::value) {
+    __shared__ uint4 stage[GatherLds<F>::NCH][ACCUM_BLOCK];
+    GatherLds<F> gq{stage};
+    accum_body<F, GatherLds<F>>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gq);
+  } else {
+    accum_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+  }
 }
 template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_merge_tail(MergeArgs<F> a) {

@@ -175,14 +175,17 @@ CTT_HD void fr_from_mont_body(const uint32_t* in, uint32_t* out, uint32_t n, uin
 
 // Converted points are stored one per 128-byte line: after the sort every lane gathers whole points by index,
 // and a 112-byte (or 72-byte) record at its natural stride would straddle two cache lines most of the time.
-// The last word of the record's padding is a flag: 1 = the affine neutral (0,0) -- the accumulate kernel tests one word
+// The word behind the coordinates is a flag: 1 = the affine neutral (0,0) -- the accumulate kernel tests one word
 // instead of all the limbs of x and y.
 template <class FD>
 constexpr uint32_t gather_stride() {
   return sizeof(Affine<FD>) + 4 <= 128 ? 128u : sizeof(Affine<FD>) + 4 <= 256 ? 256u : 512u;
 }
 template <class FD>
-constexpr uint32_t gather_flag_offset() { return gather_stride<FD>() - 4u; }
+constexpr uint32_t gather_flag_offset() { return (uint32_t)sizeof(Affine<FD>); }   // right behind the coordinates: same 16-byte chunk or the next
+// 16-byte chunks of a record that carry data (coordinates + flag word)
+template <class FD>
+constexpr uint32_t gather_chunks() { return (gather_flag_offset<FD>() + 4u + 15u) / 16u; }
 
 // Input points: reference representation -> device field (one pass per MSM; (0,0) stays (0,0))
 template <class F, class FD>
@@ -214,8 +217,56 @@ struct AccumArgs {
   uint32_t N, B, K, G;
 };
 
+// How a lane gets the record of its next entry.  The accumulation is a loop of {entry word -> record -> ~4500 (G1) to ~14000
+// (G2) instructions of addition}; read on demand, the two dependent reads (1-2 us) stall the wave once per addition, and a
+// G2 kernel runs ONE wave per SIMD.  The loop therefore requests the record of entry pos+1 (and the entry word of pos+2)
+// before the addition of entry pos and collects it afterwards.  GatherDirect is the plain form (CPU emulator, saturated
+// fields): request() only remembers the address.  The device form (hip_backend.h GatherLds) has the record delivered into
+// LDS by global_load_lds -- no registers are held while the addition runs.
 template <class F>
-CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
+struct GatherDirect {
+  const char* rec = nullptr;
+  CTT_HD void request(const char* r) { rec = r; }
+  CTT_HD void collect(Affine<F>& pt, bool& qinf) {
+    pt = *(const Affine<F>*)rec;
+    // carry-free fields: the record's flag word (convert_point_body); reference layout: test x and y
+    if constexpr (F::UNSAT) qinf = *(const uint32_t*)(rec + gather_flag_offset<F>()) != 0u; else qinf = pt.is_inf();
+  }
+};
+
+// State of a lane's walk over its K sorted entries: which bucket it is in and where that bucket ends.
+struct BucketWalk {
+  const uint32_t* bs;
+  uint32_t B, b, bend, bend2;
+  bool head0;   // the bucket the lane starts in began before the lane's range (its partial sum is a head)
+  // bucket containing position p0: bs[b] <= p0 < bs[b+1]
+  CTT_HD void start(const uint32_t* bs_, uint32_t B_, uint32_t p0) {
+    bs = bs_;
+    B = B_;
+    uint32_t lo = 0, hi = B;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (bs[mid] <= p0) lo = mid; else hi = mid;
+    }
+    b = lo;
+    head0 = bs[b] < p0;
+    bend = bs[b + 1];
+    bend2 = bs[b + 2 <= B ? b + 2 : B];   // the boundary after the next one, requested ahead: no dependent read when a bucket ends
+  }
+  // pos == bend: move to the bucket that holds position pos (empty buckets skipped; terminates because pos < bs[B])
+  CTT_HD void next(uint32_t pos) {
+    b++;
+    bend = bend2;
+    while (bend == pos) {
+      b++;
+      bend = bs[b + 1];
+    }
+    bend2 = bs[b + 2 <= B ? b + 2 : B];
+  }
+};
+
+template <class F, class G>
+CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq) {
   if (g >= a.G) return;
   const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
   const uint64_t slot = (uint64_t)w * a.G + g;
@@ -229,45 +280,47 @@ CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
   }
   const uint32_t p0 = (uint32_t)p0l;
   const uint32_t p1 = (p0l + a.K < nw) ? p0 + a.K : nw;
-  // bucket containing position p0: bs[lo] <= p0 < bs[hi]
-  uint32_t lo = 0, hi = a.B;
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (bs[mid] <= p0) lo = mid; else hi = mid;
-  }
-  uint32_t b = lo;
-  uint32_t bend = bs[b + 1];
+  BucketWalk bw;
+  bw.start(bs, a.B, p0);
   bool first_run = true;
   // the accumulator's "neutral" state lives in a flag (xyzz_madd_flag): nothing to zero when a run is flushed
   XYZZ<F> acc;
   bool empty = true;
   const uint32_t* ent = a.entries + (uint64_t)w * a.N;
+  auto record = [&](uint32_t e) {
+    return (const char*)__builtin_assume_aligned((const char*)a.points + (uint64_t)(e & 0x7fffffffu) * a.point_stride, 16);
+  };
+  const uint32_t plast = p1 - 1;
+  uint32_t e = ent[p0];
+  uint32_t e1 = ent[p0 < plast ? p0 + 1 : plast];
+  gq.request(record(e));
   for (uint32_t pos = p0; pos < p1; pos++) {
-    if (pos == bend) {
+    Affine<F> pt;
+    bool qinf;
+    gq.collect(pt, qinf);   // everything this lane has in flight is one addition old here
+    if (pos == bw.bend) {
       // bucket b is finished inside this lane's range
       if (empty) acc = XYZZ<F>::inf();
-      if (first_run && bs[b] < p0) {
+      if (first_run && bw.head0) {
         a.heads[slot] = acc;
-        hk = b;
+        hk = bw.b;
       } else {
-        a.buckets[(uint64_t)w * a.B + b] = acc;
+        a.buckets[(uint64_t)w * a.B + bw.b] = acc;
       }
       first_run = false;
       empty = true;
-      b++;
-      while (bs[b + 1] == pos) b++;  // skip empty buckets; terminates because pos < nw
-      bend = bs[b + 1];
+      bw.next(pos);
     }
-    uint32_t e = ent[pos];
-    const char* rec = (const char*)__builtin_assume_aligned((const char*)a.points + (uint64_t)(e & 0x7fffffffu) * a.point_stride, 16);
-    Affine<F> pt = *(const Affine<F>*)rec;
-    bool qinf;   // carry-free fields: the record's flag word (convert_point_body); reference layout: test x and y
-    if constexpr (F::UNSAT) qinf = *(const uint32_t*)(rec + gather_flag_offset<F>()) != 0u; else qinf = pt.is_inf();
+    gq.request(record(e1));                                        // entry pos+1 (the last one again at the end)
+    const uint32_t e2 = ent[pos + 2 < p1 ? pos + 2 : plast];
     if (!qinf) xyzz_madd_flag<F>(acc, empty, pt.x, pt.y, (e >> 31) != 0);
+    e = e1;
+    e1 = e2;
   }
   if (empty) acc = XYZZ<F>::inf();
-  const bool started_before = first_run && bs[b] < p0;
-  const bool ends_after = bend > p1;
+  const uint32_t b = bw.b;
+  const bool started_before = first_run && bw.head0;
+  const bool ends_after = bw.bend > p1;
   if (started_before) {
     a.heads[slot] = acc;
     hk = b;
@@ -281,7 +334,10 @@ CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
   a.tkey[slot] = tk;
 }
 
-// the accumulate body in the X, Y + ZZ/ZZZ-holder form (ec.h xyzz_madd_core): used for the quadratic-extension fields
+// the accumulate body in the X, Y + ZZ/ZZZ-holder form (ec.h xyzz_madd_core): used for the quadratic-extension fields.
+// Records are read on demand here: this kernel lives at the edge of its register file (483 of 512 registers, one wave per
+// SIMD), and the pipelined loop order of accum_body_xyzz -- the record collected before the bucket boundary is handled --
+// measured 11 % slower for BLS12-381 G2 on the same box (9.47 -> 10.53 ms at 2^20), with the LDS gather or without.
 template <class F, class Z>
 CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
   if (g >= a.G) return;
@@ -357,14 +413,19 @@ CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
   a.hkey[slot] = hk;
   a.tkey[slot] = tk;
 }
-template <class F>
-CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
+template <class F, class G>
+CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq) {
   if constexpr (IsFp2<F>::value && F::UNSAT) {
     ZInRegs<F> z;
     accum_body_z<F, ZInRegs<F>>(a, w, g, z);
   } else {
-    accum_body_xyzz<F>(a, w, g);
+    accum_body_xyzz<F, G>(a, w, g, gq);
   }
+}
+template <class F>
+CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
+  GatherDirect<F> gq;
+  accum_body<F, GatherDirect<F>>(a, w, g, gq);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -13,6 +13,8 @@ _lib = None
 
 
 def build():
+    if os.environ.get("EMU_LIB"):   # an emulator built elsewhere with other options (experiments)
+        return os.environ["EMU_LIB"]
     jobs = str(max(1, min(8, os.cpu_count() or 1)))
     subprocess.check_call(["make", "-s", "-j", jobs, "-C", HERE])
     return os.path.join(HERE, "libmsm_emu.so")

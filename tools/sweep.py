@@ -9,6 +9,7 @@ import itertools
 import json
 import os
 import statistics
+import zlib
 import sys
 import time
 
@@ -96,7 +97,7 @@ def main():
                 ref = bytes(r)
             print(json.dumps({"curve": curve, "log2n": log2n, "opt": dict(zip(keys, combo)), "plan": eng.last_plan(),
                               "ms_per_step": round(ms, 4), "Mpairs_s": round(n / ms / 1e3, 1),
-                              "blocking_ms": round(statistics.median(lat[2:]), 4), "same": bytes(r) == ref,
+                              "blocking_ms": round(statistics.median(lat[2:]), 4), "same": bytes(r) == ref, "crc": zlib.crc32(bytes(r)),
                               "host_ms_in_submit": round(host["submit"] / max(1, host["n"]) * 1e3, 4),
                               "host_ms_in_finish": round(host["finish"] / max(1, host["n"]) * 1e3, 4),
                               "stage_ms_blocking": {k: round(v, 3) for k, v in st.items()}}), flush=True)
