@@ -735,7 +735,8 @@ def test_window_table_cached_bases_vs_oracle(name):
             bases.close()
 
 
-@pytest.mark.parametrize("name,log2n", [("bls12_381_g1", 20), ("bn254_snarks_g1", 20)])
+@pytest.mark.parametrize("name,log2n", [("bls12_381_g1", 20), ("bn254_snarks_g1", 20), ("bn254_snarks_g1", 22),
+                                        ("bls12_381_g2", 20)])
 def test_window_table_full_size_vs_oracle(name, log2n):
     """The window-table form at a BASELINE size against the oracle (the automatic c: 20 at 2^20 bases, one set of 2^19
     buckets, 13 table rows per base), device-resident coefficients, two MSMs in flight."""
