@@ -155,6 +155,10 @@ def main():
     # every event record is a barrier packet in the queue, and all twelve cost a small pipelined MSM 15 % (2^16: 0.63 ms per
     # step against 0.55); the full stage breakdown comes from one blocking call after the timed region (stage_ms_blocking)
     eng.enable_timings(2)
+    # ... and below 2^20 pairs only every fourth MSM carries them (four records cost a 0.5 ms step 12 %: 2^16 0.53 ms per step
+    # against 0.47 without); the kernel's average duration is then over those launches of the timed region
+    ev_every = 1 if n >= (1 << 20) else 4
+    eng.set_option("timings_every", ev_every)
 
     # ---- synthetic inputs, resident in HBM -----------------------------------------------------------
     d_points = torch.empty((n, info.aff_bytes), dtype=torch.uint8, device="cuda")
@@ -191,8 +195,11 @@ def main():
                 res = xchg.finish(in_exchange)
             in_exchange = started
             if acc is not None:
-                for key, v in eng.last_timings().items():   # HIP events recorded on the engine's stream
-                    acc[key] = acc.get(key, 0.0) + v
+                t = eng.last_timings()                      # HIP events recorded on the engine's stream (zeros: not a sampled step)
+                if t["total"] > 0.0:
+                    for key, v in t.items():
+                        acc[key] = acc.get(key, 0.0) + v
+                    acc["_launches"] = acc.get("_launches", 0) + 1
             pending = nxt
         if in_exchange is not None:
             res = xchg.finish(in_exchange)
@@ -211,7 +218,8 @@ def main():
         dt = float(t.item())
 
     plan = eng.last_plan()
-    stages = {k: v / args.steps for k, v in stage_acc.items()}
+    ev_launches = int(stage_acc.pop("_launches", 0))
+    stages = {k: v / max(1, ev_launches) for k, v in stage_acc.items()}
     value = total * args.steps / dt
     lg = args.total_log2n if strong else args.log2n
     label = BASELINE_CONFIG.get((curve, lg, world)) if not strong else ("configs[3]" if (curve, lg, world) == ("bls12_381_g1", 24, 8) else None)
@@ -240,6 +248,7 @@ def main():
             "seed": seed,
         },
         "stage_ms": stages,
+        "stage_ms_note": f"HIP events around the accumulate kernel (and the whole MSM) on {ev_launches} of the {args.steps} timed steps",
     }
 
     if rank == 0:
@@ -269,7 +278,7 @@ def main():
                 "frac_vs_round1_peak_31T": mads / t_acc / INT_MAD_PEAK_R01,
                 "note": "the multiply-adds are ~78 % of the kernel's VALU instructions; every VOP3 instruction issues at the same "
                         "~4.5 cycles per wave (profiles/microbench_isa_r02.jsonl), so the kernel's own roof is its instruction "
-                        "count: profiles/pmc_r02_sq_counters_k_accum_*.txt put it at 94 % of the VALU issue slots",
+                        "count: profiles/pmc_r03_sq_counters_k_accum_*.txt: 4513 VALU instructions per mixed addition for 3542 multiply-adds",
             }
 
     # ---- the reference bench's own definition: one blocking call per iteration ----------------------------

@@ -504,13 +504,19 @@ struct HipBackend {
   // small MSM should not pay for a number it does not read.
   int timing = 0;   // 0 off, 1 every stage, 2 the accumulate stage only (what a roofline needs; an event record is a barrier
                     // packet in the queue: twelve per MSM cost a small pipelined MSM 15 % -- 2^16: 0.63 ms per step against 0.55)
-  bool stage_on(int s) const { return timing == 1 || (timing == 2 && (s == ST_ACCUM || s == ST_TOTAL)); }
+  // "timings_every" k: only every k-th MSM records its events (the others report zeros) -- a 0.5 ms pipelined MSM pays 12 % for
+  // four records, and an average over a quarter of the launches of a timed loop is as good an average
+  int timing_every = 1;
+  uint32_t timing_tick = 0;
+  bool timing_live = false;   // this MSM records (decided when its ST_TOTAL stage begins)
+  bool stage_on(int s) const { return timing_live && (timing == 1 || (timing == 2 && (s == ST_ACCUM || s == ST_TOTAL))); }
   void stage_begin(int slot, int s) {
-    if (!stage_on(s)) return;
     if (s == ST_TOTAL) {
+      timing_live = timing != 0 && (timing_tick++ % (uint32_t)(timing_every < 1 ? 1 : timing_every)) == 0u;
       for (int i = 0; i < ST_COUNT; i++) ev_used[slot][i] = 0;
       chunk = 0;
     }
+    if (!stage_on(s)) return;
     const int ch = (s == ST_TOTAL || s == ST_REDUCE) ? 0 : chunk;
     HIP_CHECK(hipEventRecord(ev_begin[slot][s][ch], stream));
     ev_used[slot][s] |= 1u << ch;

@@ -145,7 +145,9 @@ void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
 /* key: "c" window bits, "K" sorted entries per accumulate lane, "S" scalars per sort-partition workgroup, "chunks" slices a
  * host-pointer call is uploaded in (the upload of slice i+1 runs underneath the accumulation of slice i),
  * "horner_bits" bits per group of the bit Horner the device runs per window (0 = 4; the host joins the groups),
- * "host_window_sums" (legacy spelling: 1 = groups of one bit, 2 = one group per window), "timings" 1 = record the stage events ctt_hip_msm_last_timings reads.  value 0 = automatic /
+ * "host_window_sums" (legacy spelling: 1 = groups of one bit, 2 = one group per window), "timings" 1 = record the
+ * stage events ctt_hip_msm_last_timings reads (2 = the accumulate stage and the total only), "timings_every" k = only every
+ * k-th MSM records them (the others report zeros; default 1).  value 0 = automatic /
  * off.  Returns 0, or -1 for an unknown key. */
 int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
 /* r (HOST memory, `out_kind` layout) = sum coefs[i] * points[i]; d_coefs / d_points are DEVICE pointers
