@@ -211,7 +211,7 @@ struct FpU {
   // column (its Reassociate pass ranks the carry last): it starts a fresh chain from 0 and adds the carry at the end
   // with a separate 64-bit addition (v_lshl_add_u64, as expensive as a multiply) -- one extra quarter-rate
   // instruction per column, 243 per mixed addition.  CTT_FPU_CHAIN != 0 spells the chain out as inline asm so that
-  // the carry IS the first addend, with up to CTT_FPU_CHAIN (1..8) multiply-adds per asm statement.
+  // the carry IS the first addend, with up to CTT_FPU_CHAIN (1..14) multiply-adds per asm statement.
   // The host build (tests/emu, window combine) always takes the C++ form.
 #ifndef CTT_FPU_CHAIN
 #define CTT_FPU_CHAIN 4
@@ -219,7 +219,7 @@ struct FpU {
 #if defined(__HIP_DEVICE_COMPILE__) && CTT_FPU_CHAIN
 #define CTT_FPU_ASM 1
 #define CTT_MADU(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\t"
-  // 1..8 dependent multiply-adds into acc per statement (hipcc pads every asm statement with one s_nop)
+  // 1..14 dependent multiply-adds into acc per statement (hipcc pads every asm statement with one s_nop)
   CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0) {
     asm(CTT_MADU(1, 2)
         : "+v"(acc) : "v"(a0), "v"(b0) : "vcc");
@@ -251,6 +251,30 @@ struct FpU {
   CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7) {
     asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16)
         : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9), "v"(a10), "v"(b10) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9), "v"(a10), "v"(b10), "v"(a11), "v"(b11) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11, uint32_t a12, uint32_t b12) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24) CTT_MADU(25, 26)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9), "v"(a10), "v"(b10), "v"(a11), "v"(b11), "v"(a12), "v"(b12) : "vcc");
+  }
+  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11, uint32_t a12, uint32_t b12, uint32_t a13, uint32_t b13) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24) CTT_MADU(25, 26) CTT_MADU(27, 28)
+        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9), "v"(a10), "v"(b10), "v"(a11), "v"(b11), "v"(a12), "v"(b12), "v"(a13), "v"(b13) : "vcc");
   }
   // second factor = a constant of the field (an SGPR; gfx9 VOP3 reads one SGPR per instruction)
   CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0) {
@@ -285,19 +309,49 @@ struct FpU {
     asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16)
         : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7) : "vcc");
   }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9), "v"(a10), "s"(b10) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9), "v"(a10), "s"(b10), "v"(a11), "s"(b11) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11, uint32_t a12, uint32_t b12) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24) CTT_MADU(25, 26)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9), "v"(a10), "s"(b10), "v"(a11), "s"(b11), "v"(a12), "s"(b12) : "vcc");
+  }
+  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11, uint32_t a12, uint32_t b12, uint32_t a13, uint32_t b13) {
+    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24) CTT_MADU(25, 26) CTT_MADU(27, 28)
+        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9), "v"(a10), "s"(b10), "v"(a11), "s"(b11), "v"(a12), "s"(b12), "v"(a13), "s"(b13) : "vcc");
+  }
 #else
 #define CTT_FPU_ASM 0
 #endif
 
   // acc += sum_{i = LO}^{HI-1} a[i] * b[K-i]    (all bounds compile-time: the columns are unrolled by templates)
-  static constexpr int GROUP = CTT_FPU_CHAIN < 1 ? 1 : CTT_FPU_CHAIN > 8 ? 8 : CTT_FPU_CHAIN;  // multiply-adds per asm statement
+  static constexpr int GROUP = CTT_FPU_CHAIN < 1 ? 1 : CTT_FPU_CHAIN > 14 ? 14 : CTT_FPU_CHAIN;  // multiply-adds per asm statement
   template <int K, int LO, int HI>
   CTT_HD static void col_ab(uint64_t& acc, const uint32_t* a, const uint32_t* b) {
     if constexpr (LO < HI) {
 #if CTT_FPU_ASM
       constexpr int R = HI - LO < GROUP ? HI - LO : GROUP;
 #define CTT_AB(j) a[LO + j], b[K - LO - j]
-      if constexpr (R == 8) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6), CTT_AB(7));
+      if constexpr (R == 14) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6), CTT_AB(7), CTT_AB(8), CTT_AB(9), CTT_AB(10), CTT_AB(11), CTT_AB(12), CTT_AB(13));
+      else if constexpr (R == 13) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6), CTT_AB(7), CTT_AB(8), CTT_AB(9), CTT_AB(10), CTT_AB(11), CTT_AB(12));
+      else if constexpr (R == 12) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6), CTT_AB(7), CTT_AB(8), CTT_AB(9), CTT_AB(10), CTT_AB(11));
+      else if constexpr (R == 11) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6), CTT_AB(7), CTT_AB(8), CTT_AB(9), CTT_AB(10));
+      else if constexpr (R == 10) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6), CTT_AB(7), CTT_AB(8), CTT_AB(9));
+      else if constexpr (R == 9) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6), CTT_AB(7), CTT_AB(8));
+      else if constexpr (R == 8) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6), CTT_AB(7));
       else if constexpr (R == 7) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5), CTT_AB(6));
       else if constexpr (R == 6) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4), CTT_AB(5));
       else if constexpr (R == 5) madv(acc, CTT_AB(0), CTT_AB(1), CTT_AB(2), CTT_AB(3), CTT_AB(4));
@@ -333,7 +387,13 @@ struct FpU {
 #if CTT_FPU_ASM
         constexpr int R = nz_run<K, LO, HI>();
 #define CTT_MP(j) m[LO + j], UP::P[K - LO - j]
-        if constexpr (R == 8) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6), CTT_MP(7));
+        if constexpr (R == 14) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6), CTT_MP(7), CTT_MP(8), CTT_MP(9), CTT_MP(10), CTT_MP(11), CTT_MP(12), CTT_MP(13));
+        else if constexpr (R == 13) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6), CTT_MP(7), CTT_MP(8), CTT_MP(9), CTT_MP(10), CTT_MP(11), CTT_MP(12));
+        else if constexpr (R == 12) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6), CTT_MP(7), CTT_MP(8), CTT_MP(9), CTT_MP(10), CTT_MP(11));
+        else if constexpr (R == 11) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6), CTT_MP(7), CTT_MP(8), CTT_MP(9), CTT_MP(10));
+        else if constexpr (R == 10) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6), CTT_MP(7), CTT_MP(8), CTT_MP(9));
+        else if constexpr (R == 9) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6), CTT_MP(7), CTT_MP(8));
+        else if constexpr (R == 8) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6), CTT_MP(7));
         else if constexpr (R == 7) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5), CTT_MP(6));
         else if constexpr (R == 6) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4), CTT_MP(5));
         else if constexpr (R == 5) mads(acc, CTT_MP(0), CTT_MP(1), CTT_MP(2), CTT_MP(3), CTT_MP(4));

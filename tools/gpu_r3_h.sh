@@ -6,11 +6,11 @@ set -u
 OUT=$PWD/gpurun_out/r3h
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-for v in "" _w3 "" _w3; do
+for v in "" _ch14 "" _ch14; do
   LIB=$PWD/constantine_amd/libctt_msm_hip$v.so
   [ -f "$LIB" ] || continue
   echo "== variant '$v'" >> "$OUT/ab.jsonl"
-  CTT_MSM_HIP_LIB=$LIB timeout 300 python tools/sweep.py bn254_snarks_g1 22 c=16 -- pallas 20 c=16 -- vesta 20 c=16 -- bn254_snarks_g1 20 c=16 -- bn254_snarks_g1 16 c=13 -- pallas 16 c=13 >> "$OUT/ab.jsonl" 2>> "$OUT/ab.err"
+  CTT_MSM_HIP_LIB=$LIB timeout 300 python tools/sweep.py bls12_381_g2 20 c=16 -- bls12_381_g2 18 c=14 -- vesta 20 c=16 -- bn254_snarks_g2 18 c=15 >> "$OUT/ab.jsonl" 2>> "$OUT/ab.err"
 done
 python - <<'PY'
 import json
