@@ -575,6 +575,17 @@ def test_stage_timings_are_opt_in(torch_cuda):
         assert bytes(d.msm(name, ds, dp, n)) == r0
         t = d.last_timings()
         assert t["accumulate"] > 0.0 and t["total"] >= t["accumulate"]
+        # "timings_every" k: only every k-th MSM records its events, the others report zeros (bench.py below 2^20 pairs);
+        # mode 2 records the accumulate stage and the total only
+        d.enable_timings(2)
+        d.set_option("timings_every", 3)
+        seen = []
+        for _ in range(6):
+            assert bytes(d.msm(name, ds, dp, n)) == r0
+            t = d.last_timings()
+            seen.append(t["total"] > 0.0)
+            assert t["sort"] == 0.0 and (t["accumulate"] > 0.0) == seen[-1]
+        assert seen == [True, False, False, True, False, False]
     finally:
         d.close()
 
