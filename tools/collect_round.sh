@@ -11,15 +11,6 @@ REPO=$PWD
 
 timeout 600 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"
 
-# headline line, un-profiled
-timeout 600 python bench.py > "$OUT/bench_$TAG.json" 2> "$OUT/bench.err"
-
-# kernel trace + stats (rocpd database, summarised by tools/kernel_timeline.py)
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o p -- python "$REPO/bench.py" --steps 10 --warmup 2 \
-    --no-cpu-baseline --no-latency > "$OUT/bench_${TAG}_under_rocprof.json" 2> "$OUT/prof.log" )
-DB=$(find "$OUT/prof" -name "*.db" | head -1)
-python tools/kernel_timeline.py "$DB" 2 > "$OUT/rocprof_${TAG}_kernel_stats.txt" 2>> "$OUT/prof.log"   # (2: the warm-up MSMs are left out of the averages)
-
 # HBM traffic of every config the bench prints a roofline for: one counter per pass, csv output, kernel-trace only
 hbm() {  # key, bench args...
   local key=$1; shift
@@ -38,6 +29,20 @@ hbm "bls12_381_g1_2^24" --log2n 24
 hbm "bn254_snarks_g1_2^22" --curve bn254_snarks_g1 --log2n 22
 hbm "pallas_2^20" --curve pallas
 hbm "bls12_381_g2_2^20" --curve bls12_381_g2
+hbm "vesta_2^20" --curve vesta
+for k in 16 17 18 19; do hbm "bls12_381_g1_2^$k" --log2n $k; done
+# the bench lines below read their `roofline.traffic` from this run's passes
+cp "$OUT/hbm_traffic_k_accum.json" profiles/hbm_traffic_k_accum.json
+
+# headline line, un-profiled
+timeout 600 python bench.py > "$OUT/bench_$TAG.json" 2> "$OUT/bench.err"
+
+# kernel trace + stats (rocpd database, summarised by tools/kernel_timeline.py)
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o p -- python "$REPO/bench.py" --steps 10 --warmup 2 \
+    --no-cpu-baseline --no-latency > "$OUT/bench_${TAG}_under_rocprof.json" 2>> "$OUT/prof.log" )
+DB=$(find "$OUT/prof" -name "*.db" | head -1)
+python tools/kernel_timeline.py "$DB" 2 > "$OUT/rocprof_${TAG}_kernel_stats.txt" 2>> "$OUT/prof.log"   # (2: the warm-up MSMs are left out of the averages)
+
 
 # SQ counters of the accumulate kernel (own passes, kernel-trace only) for the headline and the 254/255-bit fields,
 # and the kernel statistics of those configs
