@@ -69,8 +69,14 @@ struct MsmOptions {
 // Scalars per partition block (sort pass A).  Large n: 512 blocks, two per CU, ALL of the same size -- a power-of-two slice
 // made 257 blocks of 16384 scalars out of n = 2^22 + 77777, and the one CU that got two of them doubled the time of both
 // partition kernels (measured: sort 1.00 ms instead of 0.65 ms).  Small n: at least ~64 blocks.
+// From 2^23 pairs on: 2048 blocks.  A block walks its slice in steps of 4096 scalars and, per step, all windows; with 1024 group
+// regions per window a step leaves 16 bytes in each run and the line is written back partially before the block returns to it
+// (k_part_scatter writes 5.0x its 4 bytes per record at 2^24, 1.55x at 2^22: profiles/pmc_r03_hbm_bytes_*).  Shorter slices
+// put the neighbouring pieces of a line into blocks that run at the same time: measured at 2^24, sort 3.40 ms with 32768
+// scalars per block, 3.16 with 16384, 2.85 with 8192, 3.06 with 4096 (whose count table is 250 MB); no gain at 2^22.
 static inline uint32_t plan_partition_slice(uint32_t n, uint32_t min_slice) {
-  uint32_t slice = (uint32_t)(((uint64_t)n + 511u) / 512u);
+  const uint32_t nblk = n >= (1u << 23) ? 2048u : 512u;
+  uint32_t slice = (uint32_t)(((uint64_t)n + nblk - 1u) / nblk);
   slice = (slice + 255u) & ~255u;
   if (slice < min_slice) slice = min_slice;
   while (slice > 64u && (uint64_t)slice * 64u > n) slice >>= 1;
