@@ -86,14 +86,13 @@ static inline uint32_t plan_partition_slice(uint32_t n, uint32_t min_slice) {
 static inline uint32_t plan_entries_per_lane(uint32_t n, int W, uint32_t lanes) {
   uint64_t total = (uint64_t)W * n;
   uint32_t K = (uint32_t)((total + lanes - 1) / lanes);
-  K = (K + 3u) & ~3u;
   if (K < 4) K = 4;
   // The accumulate kernel is launched as W rows of ceil(ceil(n/K)/64) one-wave workgroups, and all of them must be resident
   // at once: with even one workgroup more than wave slots, a second round runs that single wave for a whole K entries
   // (measured, BN254 2^22: c = 15 -> 17 x 241 = 4097 workgroups on 4096 slots, accumulate 6.1 ms instead of ~4.9 ms).
   // The rounding of the rows can exceed the slots for any n that is not a power of two: grow K until the grid fits.
   const uint64_t slots = lanes / 64u;
-  while ((uint64_t)W * ((((uint64_t)n + K - 1) / K + 63u) / 64u) > slots && K < 0x7ffffff0u) K += 4u;
+  while ((uint64_t)W * ((((uint64_t)n + K - 1) / K + 63u) / 64u) > slots && K < 0x7ffffff0u) K += 1u;
   return K;
 }
 
@@ -204,7 +203,6 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   p.gshift_narrow = (p.lay.r > 0 && p.gshift > 0) ? p.gshift - 1 : p.gshift;
   // entries per lane: fill the resident lanes once
   uint32_t K = o.K > 0 ? (uint32_t)o.K : plan_entries_per_lane(n, p.W, o.lanes);
-  K = (K + 3u) & ~3u;
   if (K < 4) K = 4;
   p.K = K;
   p.G = (n + K - 1) / K;
@@ -292,7 +290,6 @@ static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab
   p.NG = NG;
   p.gshift_narrow = p.gshift;  // all windows share the groups
   uint32_t K = o.K > 0 ? (uint32_t)o.K : plan_entries_per_lane(p.nent, 1, o.lanes);
-  K = (K + 3u) & ~3u;
   if (K < 4) K = 4;
   p.K = K;
   p.G = (p.nent + K - 1) / K;
@@ -534,11 +531,11 @@ struct MsmEngine {
     // (the bucket sets are cleared before that wait: the previous MSM read them in its first reduction pass, which is ahead
     // of this point on the main stream, and its tail does not touch them)
     bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
-    // Small MSMs: when the accumulate grid leaves wave slots free (2^16 pairs: 1720 one-wave workgroups on 2048 slots), the
-    // previous tail's narrow passes run next to it, and the wait moves to the start of this MSM's reduction (reduce_buckets),
-    // the first kernel that writes what the tail still reads.
+    // When the accumulate grid leaves wave slots free (submit() sees to that for a caller that keeps MSMs in flight: 5/32 of the
+    // slots up to 2^17 pairs, 1/64 of them while that costs less than half the wait), the previous tail's narrow passes run next to it, and the wait moves to the
+    // start of this MSM's reduction (reduce_buckets), the first kernel that writes what the tail still reads.
     const uint64_t accum_waves = (uint64_t)W * ((p.G + 63u) / 64u);
-    if (accum_waves * 64u * 100u > (uint64_t)opt.lanes * 85u) bk.tail_wait();
+    if (accum_waves + tail_min_free_waves() > (uint64_t)opt.lanes / 64u) bk.tail_wait();
     bk.stage_begin(sl, ST_ACCUM);
     st.d_buckets = d_buckets;
     st.d_heads = (XYZZ<FD>*)need(heads, (size_t)W * p.G * sizeof(XYZZ<FD>));
@@ -620,6 +617,20 @@ struct MsmEngine {
     if (forked) bk.tail_end();
   }
 
+  // Wave slots the accumulate grid must leave free for the previous MSM's tail to run beside it (fewer: the accumulation waits
+  // for that tail first), and how much of an accumulation submit() may spend on leaving slots free on purpose for an MSM kept
+  // in flight ...
+  static uint32_t tail_min_free_waves() {
+    static const uint32_t v = getenv("CTT_HIP_MSM_TAIL_MIN_FREE") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_TAIL_MIN_FREE")) : 16u;
+    return v;
+  }
+  // ... as a fraction of the wait it removes, which is about one tenth of a millisecond for BLS12-381 G1 and scales with the
+  // curve's addition time (the tail is a chain of dependent additions)
+  static double tail_free_cost_ratio() {
+    static const double v = getenv("CTT_HIP_MSM_TAIL_FREE_RATIO") ? atof(getenv("CTT_HIP_MSM_TAIL_FREE_RATIO")) : 0.5;
+    return v;
+  }
+
   int claim_slot(uint32_t n) {
     int sl = next_slot;
     if (slots[sl].busy) sl ^= 1;    // tickets may be finished in any order: take whichever slot is free
@@ -649,6 +660,21 @@ struct MsmEngine {
     if (slots[sl ^ 1].busy && n <= (1u << 17) && opt.K <= 0 && table_c <= 0) {
       if (po.c <= 0) po.c = choose_window_bits(n, C::BITS, opt.lanes, opt.acc_ns, opt.red_ns);
       po.lanes = (uint32_t)((uint64_t)opt.lanes * 27u / 32u);
+    } else if (slots[sl ^ 1].busy && opt.K <= 0 && table_c <= 0 && opt.lanes >= 64u * 1024u) {
+      // Larger ones: the accumulation used to wait for the previous tail -- ten dependent narrow passes, the bit Horner and the result
+      // copy, ~0.25 ms after the last wide pass, 0.1 ms longer than this MSM's sort (rocprof timeline, BLS12-381 2^20: the sort ends
+      // at 177 us, the accumulation started at 281).  With 1/64 of the wave slots left free (32 of 2048; K 128 -> 131 at 2^20) the
+      // tail finishes beside the accumulation instead.  Same box, ms per MSM with / without: BLS12-381 G1 2^19 1.72 / 1.82,
+      // 2^20 2.92 / 2.98, 2^21 5.54 / 5.59, 2^22 10.60 / 10.47; G2 2^18 2.92 / 3.13, 2^20 9.50 / 9.46 -- it pays while that share of the
+      // accumulation is well below the wait (profiles/sweep_free_wave_slots_r03.txt).
+      if (po.c <= 0) po.c = choose_window_bits(n, C::BITS, opt.lanes, opt.acc_ns, opt.red_ns);
+      int Wc;
+      window_layout(C::BITS, po.c, &Wc);
+      // 32 slots at least: a narrow pass is up to 64 waves, and a G2 wave needs a SIMD to itself (16 free slots of its 1024
+      // measured no gain, 32 did: 3.13 -> 2.92 ms at 2^18)
+      const uint32_t slots = opt.lanes / 64u, free_slots = slots / 64u > 32u ? slots / 64u : 32u;
+      const double cost_ms = (double)Wc * n * opt.acc_ns * 1e-6 * free_slots / slots, wait_ms = 0.1 * opt.acc_ns / 0.142;
+      if (cost_ms <= tail_free_cost_ratio() * wait_ms) po.lanes = opt.lanes - 64u * free_slots;
     }
     const MsmPlan p = table_c > 0 ? make_table_plan(n, C::BITS, table_c, table_n, po) : make_plan(n, C::BITS, po);
     slots[sl].plan = p;

@@ -362,7 +362,7 @@ def test_window_table_falls_back_when_memory_or_window_bits_do_not_fit(monkeypat
 def test_plan_fits_the_gpu_for_any_size():
     """The plan's roundings (msm_pipeline.h): the accumulate grid -- W rows of ceil(G/64) one-wave workgroups -- never exceeds
     the resident wave slots (one workgroup more means a second round of a single wave: measured +28 % on BN254 2^22 at c = 15),
-    the partition blocks are at most 512 + a rounding remainder and all of one size, every entry has a lane; for sizes that are
+    the partition blocks are at most 512 (2048 from 2^23 pairs on) + a rounding remainder and all of one size, every entry has a lane; for sizes that are
     and are not powers of two, both scalar widths, both occupancies, and the window-table form."""
     rng = random.Random(99)
     sizes = [1, 2, 63, 64, 65, 1000, 4096, 65536, 65537, 100000, (1 << 17) + 777, 3 << 16, 1000003, 1 << 20, (1 << 20) + 12345,
@@ -373,9 +373,9 @@ def test_plan_fits_the_gpu_for_any_size():
             # balanced windows over bits + 1 bits: r of cb + 1 bits, the others cb; c is the widest
             assert p["cb"] * p["W"] + p["r"] == bits + 1 and 0 <= p["r"] < p["W"] and p["c"] == p["cb"] + (1 if p["r"] else 0)
             assert p["Wd"] == p["W"] and p["nent"] == n and p["B"] == 1 << (p["c"] - 1)
-            assert p["G"] == -(-n // p["K"]) and p["K"] % 4 == 0
+            assert p["G"] == -(-n // p["K"]) and p["K"] >= 4
             assert p["W"] * -(-p["G"] // 64) <= max(lanes // 64, p["W"]), (n, bits, lanes, p)
-            assert p["S"] == -(-n // p["slice"]) and p["S"] <= 520, (n, p)
+            assert p["S"] == -(-n // p["slice"]) and p["S"] <= (2080 if n >= 1 << 23 else 520), (n, p)
             assert p["NG"] <= 4096 and (p["B"] >> p["gshift"]) == p["NG"] and p["B"] // p["NG"] <= 1024
             c = emu.table_window_bits(n, bits)
             assert 4 <= c <= 22
