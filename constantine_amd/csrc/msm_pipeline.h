@@ -660,13 +660,14 @@ struct MsmEngine {
     if (slots[sl ^ 1].busy && n <= (1u << 17) && opt.K <= 0 && table_c <= 0) {
       if (po.c <= 0) po.c = choose_window_bits(n, C::BITS, opt.lanes, opt.acc_ns, opt.red_ns);
       po.lanes = (uint32_t)((uint64_t)opt.lanes * 27u / 32u);
-    } else if (slots[sl ^ 1].busy && opt.K <= 0 && table_c <= 0 && opt.lanes >= 64u * 1024u) {
+    } else if (slots[sl ^ 1].busy && opt.K <= 0 && table_c <= 0 && opt.lanes >= 64u * 1024u && opt.acc_ns >= 0.1) {
       // Larger ones: the accumulation used to wait for the previous tail -- ten dependent narrow passes, the bit Horner and the result
       // copy, ~0.25 ms after the last wide pass, 0.1 ms longer than this MSM's sort (rocprof timeline, BLS12-381 2^20: the sort ends
       // at 177 us, the accumulation started at 281).  With 1/64 of the wave slots left free (32 of 2048; K 128 -> 131 at 2^20) the
       // tail finishes beside the accumulation instead.  Same box, ms per MSM with / without: BLS12-381 G1 2^19 1.72 / 1.82,
       // 2^20 2.92 / 2.98, 2^21 5.54 / 5.59, 2^22 10.60 / 10.47; G2 2^18 2.92 / 3.13, 2^20 9.50 / 9.46 -- it pays while that share of the
-      // accumulation is well below the wait (profiles/sweep_free_wave_slots_r03.txt).
+      // accumulation is well below the wait (profiles/sweep_free_wave_slots_r03.txt).  Not for the 254/255-bit G1 fields (acc_ns < 0.1):
+      // their additions are twice as fast, their tail ends before their sort does, and the free slots only cost (Pallas 2^20 1.455 / 1.433).
       if (po.c <= 0) po.c = choose_window_bits(n, C::BITS, opt.lanes, opt.acc_ns, opt.red_ns);
       int Wc;
       window_layout(C::BITS, po.c, &Wc);
