@@ -60,6 +60,8 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
     for name in exported_symbols():
+        if os.environ.get("CTT_MSM_HIP_LIB") and not hasattr(L, name):
+            continue  # an older build named explicitly for a same-box comparison (tools/): it may predate a symbol
         fn = getattr(L, name)  # AttributeError if the library does not export what the header declares
         if name.endswith("_vartime"):
             fn.argtypes = [vp, vp, vp, sz]
@@ -108,7 +110,8 @@ def lib():
     L.ctt_hip_msm_set_shard_min.argtypes = [sz]
     L.ctt_hip_msm_set_shard_min.restype = None
     L.ctt_hip_subgroup_check.argtypes = [vp, i32, vp, vp, sz, i32]
-    L.ctt_hip_fr_quotient.argtypes = [vp, i32, vp, vp, vp, vp, vp, u32]
-    L.ctt_hip_fr_quotient.restype = i32
+    if hasattr(L, "ctt_hip_fr_quotient"):
+        L.ctt_hip_fr_quotient.argtypes = [vp, i32, vp, vp, vp, vp, vp, u32]
+        L.ctt_hip_fr_quotient.restype = i32
     _lib = L
     return L
