@@ -424,11 +424,26 @@ struct HipBackend {
     on_aux = false;
     tail_pending = true;
   }
+  // "the wide reduction passes of the tail are done": what the next MSM's accumulation waits for when the tail starts early
+  // (MsmEngine::reduce_buckets) -- the narrow rest of the tail may run beside that accumulation, the wide passes may not
+  hipEvent_t ev_wide_done = nullptr;
+  bool wide_pending = false;
+  void wide_mark() {
+    if (!on_aux) return;
+    HIP_CHECK(hipEventRecord(ev_wide_done, aux));
+    wide_pending = true;
+  }
+  void wide_wait() {
+    if (!wide_pending) return;
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_wide_done, 0));
+    wide_pending = false;
+  }
   // before anything on the main stream touches what a tail still reads or writes (pyramid, trees, per-window output)
   void tail_wait() {
     if (!tail_pending) return;
     HIP_CHECK(hipStreamWaitEvent(stream, ev_tail_done, 0));
     tail_pending = false;
+    wide_pending = false;   // (the end of the tail is behind its wide passes)
   }
   static uint32_t quad_threshold() {
     static const uint32_t v = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 24576u;

@@ -536,6 +536,7 @@ struct MsmEngine {
     // start of this MSM's reduction (reduce_buckets), the first kernel that writes what the tail still reads.
     const uint64_t accum_waves = (uint64_t)W * ((p.G + 63u) / 64u);
     if (accum_waves + tail_min_free_waves() > (uint64_t)opt.lanes / 64u) bk.tail_wait();
+    bk.wide_wait();   // (nothing to wait for unless the previous reduction put wide passes on the tail stream)
     bk.stage_begin(sl, ST_ACCUM);
     st.d_buckets = d_buckets;
     st.d_heads = (XYZZ<FD>*)need(heads, (size_t)W * p.G * sizeof(XYZZ<FD>));
@@ -589,13 +590,25 @@ struct MsmEngine {
     // (only for a caller that keeps MSMs in flight -- the other slot is busy: a lone blocking call would pay the fork's
     // event record and wait, ~15 us, for nothing)
     const bool pipelining = slots[sl ^ 1].busy;
-    bool forked = false;
+    // wide_early: every pass but the first goes to the tail stream, the wide ones next to the following MSM's conversion and sort
+    // (VALU-bound additions beside memory-bound kernels); that MSM's accumulation waits for the end of the WIDE passes only
+    // (wide_mark / wide_wait) -- the narrow rest runs beside it in the wave slots its grid leaves free.
+    // Same box, ms per MSM with / without (profiles/wide_passes_on_tail_r03.txt): BLS12-381 G1 2^20 2.92 / 2.97, 2^18 0.965 / 0.977, 2^22 10.70 /
+    // 10.75; no difference for the other curves -- the kernels do slow each other down (round 2 measured the sort 0.19 -> 0.23 ms
+    // under wide passes), a quarter of the overlap is what remains.
+    static const bool wide_early = !(getenv("CTT_HIP_MSM_WIDE_EARLY") && atoi(getenv("CTT_HIP_MSM_WIDE_EARLY")) == 0);
+    bool forked = false, marked = false;
     for (int pass = 0; pass <= p.c - 2; pass++) {
       PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass, 1u};
       const uint32_t ntasks = pyr_pass_tasks(B, p.c, pass);
-      if (pipelining && !forked && pass > 0 && bk.pyr_goes_to_tail(ntasks, W)) {
+      const bool narrow = bk.pyr_goes_to_tail(ntasks, W);
+      if (pipelining && !forked && pass > 0 && (narrow || wide_early)) {
         bk.tail_begin();
         forked = true;
+      }
+      if (forked && !marked && narrow) {
+        bk.wide_mark();
+        marked = true;
       }
       bk.template launch_pyr<FD>(pa, W, ntasks);
     }
@@ -603,6 +616,7 @@ struct MsmEngine {
       bk.tail_begin();
       forked = true;
     }
+    if (forked && !marked) bk.wide_mark();
     bk.template launch_window_groups<FD>(d_out, d_wsum, W, p.c, p.h, p.ngrp);
     bk.stage_end(sl, ST_REDUCE);
 

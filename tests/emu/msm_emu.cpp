@@ -29,6 +29,8 @@ struct EmuBackend {
   void tail_begin() {}
   void tail_end() {}
   void tail_wait() {}
+  void wide_mark() {}
+  void wide_wait() {}
   void stage_chunk(int) {}
   void d2h_sync(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void h2d(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
