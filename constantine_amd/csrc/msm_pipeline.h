@@ -531,7 +531,7 @@ struct MsmEngine {
     // (the bucket sets are cleared before that wait: the previous MSM read them in its first reduction pass, which is ahead
     // of this point on the main stream, and its tail does not touch them)
     bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
-    // When the accumulate grid leaves wave slots free (submit() sees to that for a caller that keeps MSMs in flight: 5/32 of the
+    // When the accumulate grid leaves wave slots free (submit() sees to that for a caller that keeps MSMs in flight: 1/16 of the
     // slots up to 2^17 pairs, 1/64 of them while that costs less than half the wait), the previous tail's narrow passes run next to it, and the wait moves to the
     // start of this MSM's reduction (reduce_buckets), the first kernel that writes what the tail still reads.
     const uint64_t accum_waves = (uint64_t)W * ((p.G + 63u) / 64u);
@@ -673,7 +673,9 @@ struct MsmEngine {
     // (the window size is chosen for the whole chip first: fewer lanes must only lengthen K)
     if (slots[sl ^ 1].busy && n <= (1u << 17) && opt.K <= 0 && table_c <= 0) {
       if (po.c <= 0) po.c = choose_window_bits(n, C::BITS, opt.lanes, opt.acc_ns, opt.red_ns);
-      po.lanes = (uint32_t)((uint64_t)opt.lanes * 27u / 32u);
+      static const uint32_t free32 = getenv("CTT_HIP_MSM_SMALL_FREE_32NDS") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_SMALL_FREE_32NDS")) : 2u;   // round 2: 5/32 against 1/32 at 2^17 (0.69 / 0.80 ms); since the accumulation of
+      // the larger sizes stopped waiting for the tail too, 1/16 is enough (2^17 0.742 against 0.759 ms with 5/32, G2 2^16 1.048 against 1.074)
+      po.lanes = (uint32_t)((uint64_t)opt.lanes * (32u - (free32 < 31u ? free32 : 31u)) / 32u);
     } else if (slots[sl ^ 1].busy && opt.K <= 0 && table_c <= 0 && opt.lanes >= 64u * 1024u && opt.acc_ns >= 0.1) {
       // Larger ones: the accumulation used to wait for the previous tail -- ten dependent narrow passes, the bit Horner and the result
       // copy, ~0.25 ms after the last wide pass, 0.1 ms longer than this MSM's sort (rocprof timeline, BLS12-381 2^20: the sort ends
