@@ -666,15 +666,15 @@ struct MsmEngine {
     opt.acc_ns = C::ACC_NS;
     opt.red_ns = C::RED_NS;
     MsmOptions po = opt;
-    // A caller that keeps MSMs in flight gets the narrow tail of the previous MSM (last reduction passes, bit Horner, result
-    // copy: ~0.15 ms of latency, a handful of waves) run BESIDE this accumulation when the accumulate grid leaves wave slots
-    // free (accumulate_pairs); for small MSMs it pays to leave them free on purpose -- a sixth of the lanes, K grows by a
-    // fifth (measured, BLS12-381 G1 2^17, ms per MSM with two in flight: 0.69 with 17 % of the slots free, 0.80 with 5 %).
+    // A caller that keeps MSMs in flight gets the tail of the previous MSM (reduction passes behind the first, bit Horner, result
+    // copy: latency-bound, a few dozen waves at a time) run BESIDE this accumulation when the accumulate grid leaves wave slots free
+    // (accumulate_pairs); it pays to leave them free on purpose.  Up to 2^17 pairs: 1/16 of the lanes.  (Round 2 took 5/32 -- BLS12-381
+    // G1 2^17, ms per MSM with two in flight: 0.69 with 17 % of the slots free, 0.80 with 5 %; since the larger sizes stopped waiting
+    // for the tail too, 1/16 measures level or better: 2^17 0.742 against 0.759 ms with 5/32, G2 2^16 1.048 against 1.074.)
     // (the window size is chosen for the whole chip first: fewer lanes must only lengthen K)
     if (slots[sl ^ 1].busy && n <= (1u << 17) && opt.K <= 0 && table_c <= 0) {
       if (po.c <= 0) po.c = choose_window_bits(n, C::BITS, opt.lanes, opt.acc_ns, opt.red_ns);
-      static const uint32_t free32 = getenv("CTT_HIP_MSM_SMALL_FREE_32NDS") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_SMALL_FREE_32NDS")) : 2u;   // round 2: 5/32 against 1/32 at 2^17 (0.69 / 0.80 ms); since the accumulation of
-      // the larger sizes stopped waiting for the tail too, 1/16 is enough (2^17 0.742 against 0.759 ms with 5/32, G2 2^16 1.048 against 1.074)
+      static const uint32_t free32 = getenv("CTT_HIP_MSM_SMALL_FREE_32NDS") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_SMALL_FREE_32NDS")) : 2u;
       po.lanes = (uint32_t)((uint64_t)opt.lanes * (32u - (free32 < 31u ? free32 : 31u)) / 32u);
     } else if (slots[sl ^ 1].busy && opt.K <= 0 && table_c <= 0 && opt.lanes >= 64u * 1024u && opt.acc_ns >= 0.1) {
       // Larger ones: the accumulation used to wait for the previous tail -- ten dependent narrow passes, the bit Horner and the result
@@ -689,8 +689,8 @@ struct MsmEngine {
       window_layout(C::BITS, po.c, &Wc);
       // 32 slots at least: a narrow pass is up to 64 waves, and a G2 wave needs a SIMD to itself (16 free slots of its 1024
       // measured no gain, 32 did: 3.13 -> 2.92 ms at 2^18)
-      const uint32_t slots = opt.lanes / 64u, free_slots = slots / 64u > 32u ? slots / 64u : 32u;
-      const double cost_ms = (double)Wc * n * opt.acc_ns * 1e-6 * free_slots / slots, wait_ms = 0.1 * opt.acc_ns / 0.142;
+      const uint32_t nslots = opt.lanes / 64u, free_slots = nslots / 64u > 32u ? nslots / 64u : 32u;
+      const double cost_ms = (double)Wc * n * opt.acc_ns * 1e-6 * free_slots / nslots, wait_ms = 0.1 * opt.acc_ns / 0.142;
       if (cost_ms <= tail_free_cost_ratio() * wait_ms) po.lanes = opt.lanes - 64u * free_slots;
     }
     const MsmPlan p = table_c > 0 ? make_table_plan(n, C::BITS, table_c, table_n, po) : make_plan(n, C::BITS, po);
