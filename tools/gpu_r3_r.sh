@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round 3, GPU call R: the round-2 library (built from commit 628964b as constantine_amd/libctt_msm_hip_r2.so) beside the final one on one
 # box: ms per MSM with two in flight and blocking call, every BASELINE curve and the size range.   gpurun --timeout 900 -- 'bash tools/gpu_r3_r.sh'
+# The round-2 library is not kept in the tree; to rebuild it:
+#     mkdir /tmp/r2 && git archive 628964b constantine_amd/csrc | tar -x -C /tmp/r2 && make -C /tmp/r2/constantine_amd/csrc -j8 && \
+#     cp /tmp/r2/constantine_amd/libctt_msm_hip.so constantine_amd/libctt_msm_hip_r2.so
 set -u
 OUT=$PWD/gpurun_out/r3r
 mkdir -p "$OUT"; : > "$OUT/ab.jsonl"
