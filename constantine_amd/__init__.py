@@ -16,6 +16,9 @@ from .msm import (  # noqa: F401
     CachedBases,
     CttEngine,
     DeviceMsm,
+    MsmRefused,
+    msm_available,
+    msm_host,
     batchAffine_vartime,
     sum_reduce_vartime,
     multiScalarMul_vartime,

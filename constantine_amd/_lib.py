@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTT_MSM_HIP_LIB") or os.path.join(HERE, "libctt_msm_hip.so")
 
 _lib = None
-ABI_VERSION = 5  # ctt_hip_msm_abi_version() of the library this package was written against
+ABI_VERSION = 6  # ctt_hip_msm_abi_version() of the library this package was written against
 
 
 class HipLibraryMissing(RuntimeError):
@@ -24,11 +24,14 @@ def exported_symbols():
                 if par:
                     syms.append(f"ctt_{stem}_{coord}_multi_scalar_mul_{coef}_coefs_vartime_parallel")
             syms.append(f"ctt_{stem}_{coord}_batch_affine")
+            for coef in ("big", "fr"):
+                syms.append(f"ctt_hip_msm_{stem}_{coord}_{coef}")   # neutral spellings (header part 1c)
     syms += ["ctt_hip_sum_reduce", "ctt_hip_batch_affine", "ctt_hip_msm_abi_version", "ctt_hip_msm_ctx_create", "ctt_hip_msm_ctx_destroy", "ctt_hip_msm_set_option",
              "ctt_hip_msm_device", "ctt_hip_msm_device_submit", "ctt_hip_msm_device_finish", "ctt_hip_msm_sync", "ctt_hip_msm_bases_create", "ctt_hip_msm_bases_destroy",
              "ctt_hip_msm_with_bases", "ctt_hip_msm_with_bases_submit", "ctt_hip_msm_bases_create_table", "ctt_hip_msm_bases_window_bits", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
              "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream", "ctt_hip_msm_wait_stream",
-             "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min", "ctt_hip_subgroup_check", "ctt_hip_fr_quotient"]
+             "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min", "ctt_hip_subgroup_check", "ctt_hip_fr_quotient",
+             "ctt_hip_msm_host", "ctt_hip_msm_available"]
     return syms
 
 
@@ -59,11 +62,22 @@ def lib():
     _share_hip_runtime_with_torch()
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
+    # an OLDER build named explicitly for a same-box comparison (tools/ab_prev.sh) may predate a symbol: only with the explicit
+    # opt-in CTT_MSM_HIP_ALLOW_OLD_ABI=1 is a missing symbol skipped; any other library must export what the header declares
+    allow_old = bool(os.environ.get("CTT_MSM_HIP_LIB")) and os.environ.get("CTT_MSM_HIP_ALLOW_OLD_ABI") == "1"
+    missing = []
     for name in exported_symbols():
-        if os.environ.get("CTT_MSM_HIP_LIB") and not hasattr(L, name):
-            continue  # an older build named explicitly for a same-box comparison (tools/): it may predate a symbol
-        fn = getattr(L, name)  # AttributeError if the library does not export what the header declares
-        if name.endswith("_vartime"):
+        if not hasattr(L, name):
+            if allow_old:
+                missing.append(name)
+                continue
+            raise AttributeError(f"{LIB_PATH} does not export {name} (include/ctt_msm_hip.h declares it); an older build "
+                                 "for a comparison needs CTT_MSM_HIP_ALLOW_OLD_ABI=1")
+        fn = getattr(L, name)
+        if name.startswith("ctt_hip_msm_") and name.rsplit("_", 2)[-2] in ("jac", "prj") and name.rsplit("_", 1)[-1] in ("big", "fr"):
+            fn.argtypes = [vp, vp, vp, sz]
+            fn.restype = i32
+        elif name.endswith("_vartime"):
             fn.argtypes = [vp, vp, vp, sz]
             fn.restype = None
         elif name.endswith("_vartime_parallel"):
@@ -72,6 +86,16 @@ def lib():
         elif name.endswith("_batch_affine") and not name.startswith("ctt_hip"):
             fn.argtypes = [vp, vp, sz]
             fn.restype = None
+    if missing:
+        for name in missing:   # calls of a symbol the old build lacks fail loudly instead of running with default prototypes
+            def _absent(*a, _n=name, **k):
+                raise AttributeError(f"{LIB_PATH} (old ABI) has no {_n}")
+            setattr(L, name, _absent)
+    if "ctt_hip_msm_host" not in missing:
+        L.ctt_hip_msm_host.argtypes = [i32, i32, i32, vp, vp, vp, sz]
+        L.ctt_hip_msm_host.restype = i32
+        L.ctt_hip_msm_available.argtypes = []
+        L.ctt_hip_msm_available.restype = i32
     L.ctt_hip_sum_reduce.argtypes = [vp, i32, i32, vp, vp, sz, i32]
     L.ctt_hip_sum_reduce.restype = i32
     L.ctt_hip_batch_affine.argtypes = [vp, i32, i32, vp, vp, sz, i32]
@@ -110,7 +134,7 @@ def lib():
     L.ctt_hip_msm_set_shard_min.argtypes = [sz]
     L.ctt_hip_msm_set_shard_min.restype = None
     L.ctt_hip_subgroup_check.argtypes = [vp, i32, vp, vp, sz, i32]
-    if hasattr(L, "ctt_hip_fr_quotient"):
+    if "ctt_hip_fr_quotient" not in missing:
         L.ctt_hip_fr_quotient.argtypes = [vp, i32, vp, vp, vp, vp, vp, u32]
         L.ctt_hip_fr_quotient.restype = i32
     _lib = L

@@ -291,9 +291,10 @@ __device__ __forceinline__ void xyzz_add_quad_reg(XYZZ<F>& acc, const XYZZ<F>& q
 // and the host's Horner over the windows -- W c doublings whatever h is -- takes ngrp - 1 more additions per window.
 template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_window_groups(const XYZZ<F>* out, XYZZ<F>* wsum, int c, int h, int ngrp) {
+  // EC_BLOCK / 4 groups per workgroup; more groups than that (horner_bits = 1 with c >= 18: 17 .. 19 groups) go to blockIdx.y
   const uint32_t tid = threadIdx.x;
-  if (tid >= 4u * (uint32_t)ngrp) return;
-  const int role = (int)(tid & 3u), g = (int)(tid >> 2);
+  const int role = (int)(tid & 3u), g = (int)(blockIdx.y * (EC_BLOCK / 4u) + (tid >> 2));
+  if (g >= ngrp) return;   // (whole quads leave together)
   const XYZZ<F>* o = out + (size_t)blockIdx.x * c;
   const int lo = g * h;
   int hi = lo + h;
@@ -620,8 +621,9 @@ struct HipBackend {
   }
   template <class F>
   void launch_window_groups(const XYZZ<F>* out, XYZZ<F>* wsum, uint32_t W, int c, int h, int ngrp) {
-    const int nt = ((4 * ngrp + EC_BLOCK - 1) / EC_BLOCK) * EC_BLOCK;
-    hipLaunchKernelGGL(k_window_groups<F>, dim3(W), dim3(nt), 0, cur(), out, wsum, c, h, ngrp);
+    // the kernel is compiled for EC_BLOCK lanes (16 quads): the groups beyond 16 of a window take further blocks in y
+    const uint32_t gy = ((uint32_t)ngrp + EC_BLOCK / 4u - 1u) / (EC_BLOCK / 4u);
+    hipLaunchKernelGGL(k_window_groups<F>, dim3(W, gy), dim3(EC_BLOCK), 0, cur(), out, wsum, c, h, ngrp);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>

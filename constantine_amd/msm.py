@@ -64,6 +64,38 @@ def multiScalarMul_vartime_parallel(tp, curve, coefs, points, coord="jac", fr_co
     return r
 
 
+class MsmRefused(RuntimeError):
+    """A neutral host-pointer symbol returned an error code: -1 refused (bad id / length / both slots busy), -2 out of device
+    memory.  The caller that has a CPU implementation next to it (the Nim binding of INTEGRATION.md part B) falls back to it."""
+
+    def __init__(self, code):
+        super().__init__(f"ctt_hip_msm_host refused the call: {code}")
+        self.code = code
+
+
+def msm_available():
+    """ctt_hip_msm_available(): 1 when a HIP device is present, never aborts."""
+    return bool(_lib.lib().ctt_hip_msm_available())
+
+
+def msm_host(curve, coefs, points, coord="jac", fr_coefs=False, typed=True):
+    """The neutral host-pointer symbols (include/ctt_msm_hip.h part 1c): ctt_hip_msm_<curve>_<coord>_<big|fr> (typed=True,
+    "jac" / "prj") or the generic ctt_hip_msm_host (also "aff").  Same arguments and result as multiScalarMul_vartime; raises
+    MsmRefused with the symbol's status instead of aborting."""
+    info, coefs, points = _check(curve, coefs, points)
+    L = _lib.lib()
+    nco = 2 if coord == "aff" else 3
+    r = np.zeros(nco * info.coord_bytes, dtype=np.uint8)
+    if typed and coord != "aff":
+        rc = getattr(L, f"ctt_hip_msm_{info.sym}_{coord}_{'fr' if fr_coefs else 'big'}")(_ptr(r), _ptr(coefs), _ptr(points), coefs.shape[0])
+    else:
+        rc = L.ctt_hip_msm_host(info.cid, COEF_FR if fr_coefs else COEF_BIG, _COORD[coord], _ptr(r), _ptr(coefs), _ptr(points),
+                                coefs.shape[0])
+    if rc != 0:
+        raise MsmRefused(rc)
+    return r
+
+
 class DeviceMsm:
     """Device-resident MSM: inputs already in HBM (torch CUDA tensors or raw device pointers)."""
 
@@ -347,8 +379,13 @@ class CttEngine:
         # records) and c*(bits/c) doublings per base to build, one bucket set per MSM afterwards.  Automatic (None): only while
         # the table stays below TABLE_BYTES_AUTO; the library itself falls back to plain records when a table does not fit.
         if table is None:
-            n = len(bases)
-            table = n * 17 * 128 <= self.TABLE_BYTES_AUTO
+            # rows of the table the library would build: one per digit window, bits/c + 1 with c ~ log2(n) (choose_table_window_bits,
+            # msm_pipeline.h: 13 rows of 128-byte records at 2^20 bases = 1.74 GB; round 3 estimated 17 rows and dropped the table
+            # for exactly that size)
+            n = max(1, len(bases))
+            c_est = min(22, max(8, int(np.ceil(np.log2(n)))))
+            rows = -(-(CURVES[self.CURVE].scalar_bits + 1) // c_est)
+            table = n * rows * 128 <= self.TABLE_BYTES_AUTO
         return CachedBases(self.CURVE, bases, table=table)
 
     def msm_with_cached_scalars(self, coeffs_desc, bases):

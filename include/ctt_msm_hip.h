@@ -129,13 +129,36 @@ CTT_BATCH_AFFINE_DECL(pallas_ec_prj, pallas_ec_aff)
 CTT_BATCH_AFFINE_DECL(vesta_ec_jac, vesta_ec_aff)
 CTT_BATCH_AFFINE_DECL(vesta_ec_prj, vesta_ec_aff)
 
-/* ---- Part 2: device-resident interface ------------------------------------------------------------------ */
-typedef struct ctt_hip_msm_ctx ctt_hip_msm_ctx;
-
+/* ---- Part 1c: neutral host-pointer symbols (SURVEY §8b "replacement plan") ----------------------------------------
+ * The same host-pointer MSM as Part 1 under names nothing in Constantine exports, for a binding INSIDE libconstantine: the
+ * templates of bindings/c_curve_decls.nim:418-431 and bindings/c_curve_decls_parallel.nim:33-45 keep `libExport`ing the
+ * ctt_<EC>_multi_scalar_mul_* names and `importc` these (INTEGRATION.md part B), so a static libconstantine.a defines every
+ * name once.  Same argument meaning as Part 1 (host pointers, caller-owned, r out-only); the difference is the `int` they
+ * return, the error channel the Constantine names lack: 0 = r holds the result; -1 = bad id, len above 2^31-1, or both
+ * in-flight slots of the default context taken by tickets of Part 2; -2 = out of device memory.  r is untouched on an error
+ * and the binding runs the reference's CPU path instead.  ctt_hip_msm_available() never aborts: 1 when a HIP device is
+ * present (the probe a binding makes once), else 0. */
 enum { CTT_HIP_BLS12_381_G1 = 0, CTT_HIP_BLS12_381_G2 = 1, CTT_HIP_BN254_SNARKS_G1 = 2,
        CTT_HIP_BN254_SNARKS_G2 = 3, CTT_HIP_PALLAS = 4, CTT_HIP_VESTA = 5 };
 enum { CTT_HIP_COEF_BIG = 0, CTT_HIP_COEF_FR = 1 };
 enum { CTT_HIP_OUT_AFF = 0, CTT_HIP_OUT_JAC = 1, CTT_HIP_OUT_PRJ = 2 };
+int ctt_hip_msm_available(void);
+int ctt_hip_msm_host(int curve, int coef_kind, int out_kind, void* r, const void* coefs, const void* points, size_t len);
+#define CTT_HIP_MSM_DECL_NEUTRAL(STEM, AFF, BIG, FR)                                                        \
+  int ctt_hip_msm_##STEM##_jac_big(STEM##_jac* r, const BIG coefs[], const AFF points[], size_t len);       \
+  int ctt_hip_msm_##STEM##_jac_fr(STEM##_jac* r, const FR coefs[], const AFF points[], size_t len);         \
+  int ctt_hip_msm_##STEM##_prj_big(STEM##_prj* r, const BIG coefs[], const AFF points[], size_t len);       \
+  int ctt_hip_msm_##STEM##_prj_fr(STEM##_prj* r, const FR coefs[], const AFF points[], size_t len);
+CTT_HIP_MSM_DECL_NEUTRAL(bls12_381_g1, bls12_381_g1_aff, big255, bls12_381_fr)
+CTT_HIP_MSM_DECL_NEUTRAL(bls12_381_g2, bls12_381_g2_aff, big255, bls12_381_fr)
+CTT_HIP_MSM_DECL_NEUTRAL(bn254_snarks_g1, bn254_snarks_g1_aff, big254, bn254_snarks_fr)
+CTT_HIP_MSM_DECL_NEUTRAL(bn254_snarks_g2, bn254_snarks_g2_aff, big254, bn254_snarks_fr)
+CTT_HIP_MSM_DECL_NEUTRAL(pallas_ec, pallas_ec_aff, big255, pallas_fr)
+CTT_HIP_MSM_DECL_NEUTRAL(vesta_ec, vesta_ec_aff, big255, vesta_fr)
+
+/* ---- Part 2: device-resident interface ------------------------------------------------------------------ */
+typedef struct ctt_hip_msm_ctx ctt_hip_msm_ctx;
+
 
 int ctt_hip_msm_abi_version(void);
 /* One context = one GPU, its streams, one grow-only workspace. NULL ctx in the calls below = process default

@@ -7,7 +7,9 @@
  *   out.bin: bls12_381_g1_jac (parallel symbol, big coefs) | bls12_381_g1_prj (serial symbol, big coefs)
  *            | bls12_381_g1_jac (parallel symbol again, the call sharded over two contexts on device 0:
  *              ctt_hip_msm_set_devices) | bls12_381_g1_jac (cached bases with a window table:
- *              ctt_hip_msm_bases_create_table + ctt_hip_msm_with_bases) | n bytes of ctt_hip_subgroup_check flags
+ *              ctt_hip_msm_bases_create_table + ctt_hip_msm_with_bases) | bls12_381_g1_jac (neutral typed symbol
+ *              ctt_hip_msm_bls12_381_g1_jac_big -- what the Nim binding of INTEGRATION.md part B imports) | bls12_381_g1_prj
+ *              (neutral generic symbol ctt_hip_msm_host) | n bytes of ctt_hip_subgroup_check flags
  * Built and driven by tests/test_gpu_parity.py::test_c_program_through_the_header. */
 #include <stdint.h>
 #include <stdio.h>
@@ -50,12 +52,22 @@ int main(int argc, char** argv) {
   if (ctt_hip_msm_with_bases(NULL, bases, CTT_HIP_COEF_BIG, CTT_HIP_OUT_JAC, &rt, coefs, (size_t)n, 0) != 0) return 12;
   ctt_hip_msm_bases_destroy(NULL, bases);
 
+  /* the neutral symbols: same call, status returned (0 = done); a bad curve id is refused, not aborted on */
+  bls12_381_g1_jac rn;
+  bls12_381_g1_prj rg;
+  if (ctt_hip_msm_available() != 1) return 13;
+  if (ctt_hip_msm_bls12_381_g1_jac_big(&rn, coefs, points, (size_t)n) != 0) return 14;
+  if (ctt_hip_msm_host(CTT_HIP_BLS12_381_G1, CTT_HIP_COEF_BIG, CTT_HIP_OUT_PRJ, &rg, coefs, points, (size_t)n) != 0) return 15;
+  if (ctt_hip_msm_host(17, CTT_HIP_COEF_BIG, CTT_HIP_OUT_PRJ, &rg, coefs, points, (size_t)n) != -1) return 16;
+
   f = fopen(argv[2], "wb");
   if (!f) return 7;
   fwrite(&rj, sizeof rj, 1, f);
   fwrite(&rp, sizeof rp, 1, f);
   fwrite(&rs, sizeof rs, 1, f);
   fwrite(&rt, sizeof rt, 1, f);
+  fwrite(&rn, sizeof rn, 1, f);
+  fwrite(&rg, sizeof rg, 1, f);
   fwrite(ok, 1, n, f);
   fclose(f);
   free(ok);

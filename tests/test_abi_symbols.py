@@ -43,7 +43,20 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert len([s for s in declared if s.endswith('_batch_affine') and 'hip' not in s]) == 12
+    assert len([s for s in declared if re.fullmatch(r"ctt_hip_msm_[a-z0-9_]+_(jac|prj)_(big|fr)", s)]) == 24   # neutral set
     assert L.ctt_hip_msm_abi_version() == _lib.ABI_VERSION
+
+
+def test_library_exports_nothing_but_the_c_abi():
+    """the .so is built with -fvisibility=hidden; `nm -D --defined-only` shows the declared ctt_* symbols and
+    nothing else (no C++ symbols of the engine, no device stubs, no per-curve operation tables)."""
+    from constantine_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    names = sorted({line.split()[-1] for line in out.splitlines() if line.strip()})
+    declared = set(_declared_symbols())
+    extra = [s for s in names if s not in declared]
+    assert not extra, extra[:20]
+    assert set(names) == declared
 
 
 def test_host_only_point_sum_matches_oracle():

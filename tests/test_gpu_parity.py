@@ -346,8 +346,18 @@ def test_horner_groups_and_merge_without_host_wait(dev, torch_cuda):
                 dev.set_option("K", K)
                 dev.set_option("horner_bits", hb)
                 assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (label, c, hb, K, dev.last_plan())
+        # more than 16 groups per window (horner_bits = 1, or the legacy host_window_sums = 1, with c >= 18 gives
+        # 17 .. 19 groups = 68 .. 76 lanes: the groups beyond a workgroup's 16 quads run in further blocks)
+        expect = bytes(cref.msm(name, sc, pts, nthreads=NT)[0])
+        ds = _to_dev(torch, sc)
+        for c, hb, hws in ((18, 1, 0), (19, 1, 0), (20, 1, 0), (20, 0, 1), (18, 0, 1), (20, 2, 0)):
+            dev.set_option("c", c)
+            dev.set_option("K", 0)
+            dev.set_option("horner_bits", hb)
+            dev.set_option("host_window_sums", hws)
+            assert bytes(dev.msm(name, ds, dp, n, coord="aff")) == expect, (c, hb, hws, dev.last_plan())
     finally:
-        for k in ("c", "K", "horner_bits"):
+        for k in ("c", "K", "horner_bits", "host_window_sums"):
             dev.set_option(k, 0)
 
 
@@ -803,13 +813,15 @@ def test_c_program_through_the_header(tmp_path):
         f.write(pts.tobytes())
     subprocess.check_call([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
     out = open(tmp_path / "out.bin", "rb").read()
-    assert len(out) == 4 * 144 + n
+    assert len(out) == 6 * 144 + n
     expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
     assert curve.jac_from_bytes(out[:144]) == expect
     assert curve.prj_from_bytes(out[144:288]) == expect
     assert curve.jac_from_bytes(out[288:432]) == expect          # sharded over two contexts
     assert curve.jac_from_bytes(out[432:576]) == expect          # cached bases with a window table
-    assert out[576:] == b"\x01" * n                                # every generated point is in the subgroup
+    assert curve.jac_from_bytes(out[576:720]) == expect          # neutral typed symbol (what the Nim binding imports)
+    assert curve.prj_from_bytes(out[720:864]) == expect          # neutral generic symbol
+    assert out[864:] == b"\x01" * n                                # every generated point is in the subgroup
 
 
 def test_concurrent_callers_are_serialised():
