@@ -51,6 +51,92 @@ BASELINE_CONFIG = {("bls12_381_g1", 20, 1): "configs[1]", ("bn254_snarks_g1", 22
                    ("bls12_381_g2", 20, 1): "configs[4]", ("pallas", 20, 1): "configs[4]", ("vesta", 20, 1): "configs[4]"}
 
 
+# What the reference publishes for this path (terminal screenshots linked from README-PERFORMANCE.md:89-97,
+# other hardware): printed beside `cpu_baseline` as external reference lines, never as a baseline of this box.
+PUBLISHED_REFERENCE = [
+    {"curve": "bls12_381_g1", "n": 1 << 10, "points_per_s": 0.617e6, "threads": 16, "hw": "AMD Ryzen 7 7840U (8C/16T laptop)"},
+    {"curve": "bls12_381_g1", "n": 1 << 16, "points_per_s": 1.28e6, "threads": 16, "hw": "AMD Ryzen 7 7840U (8C/16T laptop)"},
+    {"curve": "bls12_381_g1", "n": 1 << 18, "points_per_s": 1.62e6, "threads": 16, "hw": "AMD Ryzen 7 7840U (8C/16T laptop)"},
+    {"curve": "bn254_snarks_g1", "n": 1 << 16, "points_per_s": 3.42e6, "threads": 36, "hw": "Intel i9-9980XE (18C/36T, 4.1 GHz)"},
+    {"curve": "bn254_snarks_g1", "n": 1 << 22, "points_per_s": 6.04e6, "threads": 36, "hw": "Intel i9-9980XE (18C/36T, 4.1 GHz)"},
+]
+
+
+def reference_toolchain():
+    """probe for Nim.  Constantine itself is only timed when `nim` and `nimble` AND a checkout
+    of the reference ($CTT_REFERENCE_DIR, default /root/reference -- absent on the GPU box) are all present; otherwise the port is."""
+    import shutil
+    nim, nimble = shutil.which("nim"), shutil.which("nimble")
+    ref = os.environ.get("CTT_REFERENCE_DIR", "/root/reference")
+    have_ref = os.path.exists(os.path.join(ref, "constantine.nimble"))
+    return {"nim": nim, "nimble": nimble, "reference_checkout": ref if have_ref else None,
+            "can_run_reference": bool(nim and nimble and have_ref)}
+
+
+def run_reference_bench(ref_dir, curve):
+    """`CC=clang nimble bench_ec_msm_<curve>` of the reference itself (constantine.nimble:1109-1113); returns its raw output lines
+    that carry a multi-scalar-mul timing.  Only reached when reference_toolchain()["can_run_reference"]."""
+    task = {"bls12_381_g1": "bench_ec_msm_bls12_381_g1", "bn254_snarks_g1": "bench_ec_msm_bn254_snarks_g1"}.get(curve)
+    if not task:
+        return None
+    env = dict(os.environ, CC=os.environ.get("CC", "clang"))
+    try:
+        out = subprocess.run(["nimble", task], cwd=ref_dir, env=env, capture_output=True, text=True, timeout=1800).stdout
+    except Exception as e:   # noqa: BLE001
+        return [f"nimble {task} failed: {e}"]
+    return [ln.strip() for ln in out.splitlines() if "multi-scalar-mul" in ln.lower() or "msm" in ln.lower()][:40]
+
+
+def cpu_only_leg(args):
+    """BASELINE.json configs[0]: bench_ec_msm_bls12_381_g1.nim, 2^10 random (scalar,point) pairs, CPU threadpool reference --
+    plumbing, no GPU.  Times the oracle port (oracle/msm_ref.cpp, reference algorithm incl. its window choice) on this host's
+    cores and checks it bit-for-bit against the big-integer oracle (oracle/pyoracle.py).  Prints one JSON line."""
+    from oracle import cref
+    from oracle import pyoracle as po
+    curve, n = args.curve, 1 << args.log2n
+    info = po.CURVES[curve]
+    seed = 0x5EED0000 + 1
+    pts = cref.gen_points(curve, seed, n)
+    sc = cref.synth_scalars(seed + 1, n, info.scalar_bits)
+    budget = host_cpu_budget()
+    cores = min(os.cpu_count() or 1, 2 * budget)
+    flags = cref.build_native()
+    iters = max(1, 10000 // n)           # the reference bench's iteration count (bench_elliptic_parallel_template.nim:157-164)
+    runs, runs1 = [], []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        for _ in range(iters):
+            exp, c_used = cref.msm(curve, sc, pts, nthreads=cores)
+        runs.append((time.perf_counter() - t1) / iters)
+        t1 = time.perf_counter()
+        for _ in range(iters):
+            exp1, _ = cref.msm(curve, sc, pts, nthreads=1)
+        runs1.append((time.perf_counter() - t1) / iters)
+    m = min(n, 1 << 10)                  # the big-integer oracle is pure Python: bounded sample
+    expect = info.msm_pippenger([int.from_bytes(bytes(x), "little") for x in sc[:m]], [info.aff_from_bytes(bytes(x)) for x in pts[:m]])
+    got_m, _ = cref.msm(curve, sc[:m], pts[:m], nthreads=cores)
+    tool = reference_toolchain()
+    out = {
+        "metric": f"MSM points/sec, {curve}, 2^{args.log2n} random pairs, CPU only (BASELINE.json configs[0])",
+        "value": n / statistics.median(runs), "unit": "points/s", "n_gpus": 0, "higher_is_better": True,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{curve} MSM, 2^{args.log2n} pairs, oracle port on the host cores (no GPU)", "seed": seed,
+                   "window_bits": c_used, "iters_per_run": iters},
+        "cpu_baseline": {"value": n / statistics.median(runs), "unit": "points/s", "cores": cores, "kind": "port",
+                         "serial_value": n / statistics.median(runs1),
+                         "sample": f"all 2^{args.log2n} pairs, median of 5 runs of {iters} calls, {cores} threads on a {budget}-CPU quota "
+                                   f"({cpu_model()}); {flags}; oracle/msm_ref.cpp is a restatement of Constantine's algorithm, not "
+                                   "Constantine (no endomorphism, no assembly)"},
+        "parity_port_vs_bigint_oracle": bool(info.aff_from_bytes(bytes(got_m)) == expect),
+        "parity_threads_vs_serial": bool(bytes(exp) == bytes(exp1)),
+        "reference_toolchain": tool,
+        "published_reference": [r for r in PUBLISHED_REFERENCE if r["curve"] == curve],
+    }
+    if tool["can_run_reference"]:
+        out["reference_bench_output"] = run_reference_bench(tool["reference_checkout"], curve)
+    print(json.dumps(out), flush=True)
+
+
 def host_cpu_budget():
     """CPUs this process may actually use: min(affinity, cgroup quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -111,7 +197,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL); gloo is for "
                     "exercising the multi-rank path on a single-GPU box together with --all-ranks-on-device")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="testing: put every rank on this GPU")
+    ap.add_argument("--cpu-only", action="store_true", help="BASELINE.json configs[0]: the CPU port against the big-integer oracle, "
+                    "no GPU (use with --log2n 10)")
     args = ap.parse_args()
+
+    if args.cpu_only:
+        return cpu_only_leg(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -227,8 +318,12 @@ def main():
     out = {
         "metric": ("MSM points/sec, BLS12-381 G1, 2^20 random pairs" if (curve == "bls12_381_g1" and lg == 20 and not strong)
                    else f"MSM points/sec, {curve}, 2^{lg} random pairs")
-                  + (" in total" if strong else f" per GPU ({world} x 2^{lg} pairs in one MSM)" if world > 1 else ""),
+                  + (" in total" if strong else f" per GPU ({world} x 2^{lg} pairs in one MSM)" if world > 1 else "")
+                  + "; pipelined throughput, 2 MSMs in flight, inputs resident in HBM",
         "value": value,
+        "value_kind": "pipelined: steps / wall time with two complete MSMs in flight (the host tail of MSM i runs under the GPU work of "
+                      "MSM i+1); `value_blocking` = N / latency of ONE blocking call (SURVEY 8d's definition, the reference bench's), "
+                      "`value_hostptr` = the same through the Constantine symbol on pageable host arrays (PCIe included)",
         "unit": "points/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -251,8 +346,17 @@ def main():
         "stage_ms_note": f"HIP events around the accumulate kernel (and the whole MSM) on {ev_launches} of the {args.steps} timed steps",
     }
 
+    if world > 1:
+        # what the collective library reports, not what the launcher asked for: the first RCCL/gloo collective of the run was the
+        # barrier of the first fence(); here every rank contributes 1 and rank 0 prints the sum next to the backend's own count
+        ones = torch.ones(1, dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        out["collective"] = {"backend": dist.get_backend(), "rccl_ranks_seen": int(ones.item()), "world_size": dist.get_world_size(),
+                             "devices": torch.cuda.device_count(), "rank0_device": torch.cuda.get_device_name(local_rank)}
+
     if rank == 0:
-        # ---- roofline of the dominant kernel (bucket accumulation, k_accum) -----------------------------
+        # ---- roofline of the dominant kernel (bucket accumulation, k_accum); N > 1: rank 0's launches (every rank runs the same
+        # kernel over its own shard) -----------------------------
         t_acc = stages.get("accumulate", 0.0) * 1e-3
         alg_bytes = n * BYTES_PER_PAIR.get(curve, 128)  # N x (scalar + affine point), one launch = all windows
         achieved = alg_bytes / t_acc / 1e9 if t_acc > 0 else 0.0
@@ -260,7 +364,7 @@ def main():
         tr_path = os.path.join(ROOT, "profiles", "hbm_traffic_k_accum.json")
         if os.path.exists(tr_path):
             try:
-                traffic = json.load(open(tr_path)).get(f"{curve}_2^{args.log2n}")
+                traffic = json.load(open(tr_path)).get(f"{curve}_2^{int(np.log2(n)) if n & (n - 1) == 0 else -1}")
                 traffic_src = "profiles/hbm_traffic_k_accum.json (rocprofv3 --pmc passes of an earlier run of this workload, not measured in this run)"
             except Exception:
                 traffic = None
@@ -292,6 +396,7 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
         lat = lat[2:]
         out["latency_ms_blocking"] = statistics.median(lat)
+        out["value_blocking"] = n / statistics.median(lat) * 1e3
         out["latency_note"] = ("median of 10 single blocking ctt_hip_msm_device calls after 2 warm-ups, inputs resident in HBM "
                                f"(min {min(lat):.3f}, max {max(lat):.3f}); points/s at this latency = {n / statistics.median(lat) * 1e3:.4g}")
         eng.enable_timings(True)
@@ -310,6 +415,7 @@ def main():
             hp.append((time.perf_counter() - t1) * 1e3)
         hp = hp[2:]
         out["hostptr_ms"] = statistics.median(hp)
+        out["value_hostptr"] = n / statistics.median(hp) * 1e3
         out["hostptr_note"] = (f"median of 5 calls of ctt_{info.sym}_jac_multi_scalar_mul_big_coefs_vartime"
                                f"{'_parallel' if info.has_parallel else ''} on pageable host arrays after 2 warm-ups "
                                f"(H2D of {n * (32 + info.aff_bytes) >> 20} MiB included): {n / statistics.median(hp) * 1e3:.4g} points/s")
@@ -378,6 +484,12 @@ def main():
                           f"{cores} threads on a {budget}-CPU cgroup quota ({os.cpu_count()} logical CPUs visible, {cpu_model()}); {flags}",
             }
             out["parity_vs_oracle_on_sample"] = bool(bytes(got) == bytes(exp))
+            tool = reference_toolchain()
+            out["cpu_baseline"]["reference_toolchain"] = tool
+            out["cpu_baseline"]["published_reference"] = [r for r in PUBLISHED_REFERENCE if r["curve"] == curve]
+            if tool["can_run_reference"] and os.environ.get("CTT_RUN_REFERENCE_BENCH") == "1":
+                # Constantine itself (minutes of Nim compilation): opt-in, so that the default run still finishes in minutes
+                out["cpu_baseline"]["reference_bench_output"] = run_reference_bench(tool["reference_checkout"], curve)
         print(json.dumps(out), flush=True)
 
     eng.close()

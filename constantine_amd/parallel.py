@@ -29,7 +29,9 @@ class ShardExchange:
     keeps MSMs in flight finishes exchange i after it has started exchange i+1 (bench.py); msm_sharded() below is the
     blocking form."""
 
-    def __init__(self, curve, group=None, device=None):
+    def __init__(self, curve, group=None, device=None, always_collective=False):
+        """always_collective: run the all_gather even in a world of one rank (tests: the first RCCL collective this code
+        issues should not be on an 8-GPU scaling run)."""
         import torch
         import torch.distributed as dist
         self.curve = curve
@@ -37,8 +39,9 @@ class ShardExchange:
         self.group = group
         self.dist = dist
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.collective = self.world > 1 or (always_collective and dist.is_available() and dist.is_initialized())
         self.slot = 0
-        if self.world > 1:
+        if self.collective:
             dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
             nb = self.info.aff_bytes
             self.mine = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -48,7 +51,7 @@ class ShardExchange:
         import torch
         part = np.ascontiguousarray(part, dtype=np.uint8)
         assert part.shape == (self.info.aff_bytes,)
-        if self.world == 1:
+        if not self.collective:
             return (None, part)
         k = self.slot
         self.slot ^= 1
@@ -65,8 +68,8 @@ class ShardExchange:
         return ec_sum_affine(self.curve, allp, coord=coord)
 
 
-def msm_sharded(curve, local_msm, group=None, device=None, coord="aff"):
+def msm_sharded(curve, local_msm, group=None, device=None, coord="aff", always_collective=False):
     """local_msm() -> this rank's partial result as affine bytes (uint8[2*coord]).
     Gathers the partials of all ranks and returns the combined point (same on every rank)."""
-    x = ShardExchange(curve, group=group, device=device)
+    x = ShardExchange(curve, group=group, device=device, always_collective=always_collective)
     return x.finish(x.start(local_msm()), coord=coord)

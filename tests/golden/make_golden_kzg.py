@@ -12,7 +12,7 @@ Sources (reference-relative):
       -> kzg4844_srs_g1_lagrange.bin   (4096 x 48 bytes, file order)
   tests/protocol_ethereum_eip4844_deneb_kzg/blob_to_kzg_commitment/kzg-mainnet/*valid_blob*/data.yaml
       -> kzg4844_blob_to_commitment.json : [[case, zlib+base64(blob), commitment_hex], ...]
-      (the four structured blobs and one of the random ones; the other two random blobs add nothing but 256 KB)
+      (all 7 valid blobs -- four structured, three random -- and the 4 rejected ones: every case of the reference's directory)
 """
 import base64
 import glob
@@ -35,7 +35,6 @@ def main():
 
     cases = []
     base = f"{REF}/tests/protocol_ethereum_eip4844_deneb_kzg/blob_to_kzg_commitment/kzg-mainnet"
-    random_kept = 0
     for d in sorted(glob.glob(f"{base}/*valid_blob*")):
         if "invalid" in d:
             continue
@@ -43,10 +42,6 @@ def main():
         blob = bytes.fromhex(re.search(r"blob: '0x([0-9a-f]+)'", t).group(1))
         out = re.search(r"output: '0x([0-9a-f]+)'", t).group(1)
         z = zlib.compress(blob, 9)
-        if len(z) > 4096:
-            if random_kept:
-                continue
-            random_kept += 1
         cases.append([os.path.basename(d), base64.b64encode(z).decode(), out])
     # invalid blobs (wrong length / a field element >= r): the reference returns an error status, output is null
     for d in sorted(glob.glob(f"{base}/*invalid_blob*")):
@@ -71,18 +66,20 @@ def make_proofs(commit_cases):
       tests/protocol_ethereum_eip4844_deneb_kzg/compute_blob_kzg_proof/kzg-mainnet/*/data.yaml
           -> "compute_blob_kzg_proof": [[case, blob_case, commitment_hex, proof_hex | null], ...]"""
     import hashlib
-    known = {}
+    known, known_len = {}, {}
     for name, z, _ in commit_cases:
         blob = bytes(int(z[4:])) if z.startswith("LEN:") else zlib.decompress(base64.b64decode(z))
         if not z.startswith("LEN:"):
             known[hashlib.sha256(blob).digest()] = name
+        else:
+            known_len[len(blob)] = name      # the wrong-length blobs are random data: what is tested is the length
     out = {"compute_kzg_proof": [], "compute_blob_kzg_proof": []}
     root = f"{REF}/tests/protocol_ethereum_eip4844_deneb_kzg"
     for d in sorted(glob.glob(f"{root}/compute_kzg_proof/kzg-mainnet/*")):
         t = open(f"{d}/data.yaml").read()
         blob = bytes.fromhex(re.search(r"blob: '0x([0-9a-f]*)'", t).group(1))
         z = re.search(r"z: '0x([0-9a-f]*)'", t).group(1)
-        ref = known.get(hashlib.sha256(blob).digest())
+        ref = known.get(hashlib.sha256(blob).digest()) or known_len.get(len(blob))
         if ref is None:
             continue
         m = re.search(r"output: \['0x([0-9a-f]+)',\s*'0x([0-9a-f]+)'\]", t)
@@ -92,7 +89,7 @@ def make_proofs(commit_cases):
         t = open(f"{d}/data.yaml").read()
         blob = bytes.fromhex(re.search(r"blob: '0x([0-9a-f]*)'", t).group(1))
         com = re.search(r"commitment: '0x([0-9a-f]*)'", t).group(1)
-        ref = known.get(hashlib.sha256(blob).digest())
+        ref = known.get(hashlib.sha256(blob).digest()) or known_len.get(len(blob))
         if ref is None:
             continue
         m = re.search(r"output: '0x([0-9a-f]+)'", t)

@@ -119,20 +119,35 @@ def test_gpu_sum_reduce_vs_oracle(name):
 
 @pytest.mark.gpu
 def test_gpu_device_resident_primitives_at_scale():
-    """2^20 points in HBM: sum_reduce equals the MSM with all scalars 1; batch_affine inverts a device-made blow-up."""
+    """2^20 points in HBM: sum_reduce against the ORACLE (an MSM of the port with every scalar 1, which the engine's own MSM must
+    equal too); batch_affine of 2^16 Jacobian and projective points with random Z (built on the host with the big-integer field,
+    neutrals sprinkled in) against the affine points they were made from, and the Z = 1 / Z = 0 rows at 2^20."""
+    import os
     import torch
     from constantine_amd import DeviceMsm, CURVES
     name = "bls12_381_g1"
     info = CURVES[name]
     n = 1 << 20
+    nt = max(1, min(32, os.cpu_count() or 1))
     eng = DeviceMsm(0)
     d_pts = torch.empty((n, info.aff_bytes), dtype=torch.uint8, device="cuda")
     eng.gen_points(name, 77, n, d_pts)
+    pts = d_pts.cpu().numpy()
     ones = np.zeros((n, 32), dtype=np.uint8)
     ones[:, 0] = 1
-    want = eng.msm(name, torch.from_numpy(ones).cuda(), d_pts, n, coord="aff")
-    got = eng.sum_reduce(name, d_pts, n, coord="aff")
-    assert bytes(got) == bytes(want)
+    want = bytes(cref.msm(name, ones, pts, nthreads=nt)[0])          # the oracle's sum of the 2^20 points
+    assert bytes(eng.sum_reduce(name, d_pts, n, coord="aff")) == want
+    assert bytes(eng.msm(name, torch.from_numpy(ones).cuda(), d_pts, n, coord="aff")) == want
+    # random Z: 2^16 points blown up on the host, converted back on the device
+    m = 1 << 16
+    rng = random.Random(99)
+    for kind in ("jac", "prj"):
+        src, expect = make_nonaffine(name, pts[:m], kind, rng, neutral_at=set(range(0, m, 997)) | {m - 1})
+        d_src = torch.from_numpy(src).cuda()
+        d_out = torch.empty((m, info.aff_bytes), dtype=torch.uint8, device="cuda")
+        eng.batch_affine(name, d_out, d_src, m, src_coord=kind)
+        torch.cuda.synchronize()
+        assert bytes(d_out.cpu().numpy()) == bytes(expect), kind
     # Jacobian with Z = 1 (Montgomery one) must come back unchanged; Z = 0 rows become the neutral
     one = np.frombuffer(po.CURVES[name].F.to_mont_bytes(1), dtype=np.uint8)
     d_jac = torch.empty((n, 3 * info.coord_bytes), dtype=torch.uint8, device="cuda")
