@@ -102,15 +102,7 @@ CTT_HD void xyzz_madd_flag(XYZZ<F>& acc, bool& empty, const F& qx, const F& qy_i
   }
   F qy = fcneg_lz<F, M, L1>(qy_in, neg);                      // < 3, lazy: feeds S2 only
   F U2, S2;
-#if defined(CTT_MADD_SERIAL) && defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_sched_barrier(0);
-  U2 = F::mul(qx, acc.zz);
-  __builtin_amdgcn_sched_barrier(0);
-  S2 = F::mul(qy, acc.zzz);
-  __builtin_amdgcn_sched_barrier(0);
-#else
   fmul_pair<F>(qx, acc.zz, qy, acc.zzz, U2, S2);              // 2*2, 3*2
-#endif
   F P = fsub_lz<F, XB, L2>(U2, acc.x);                        // < 2 + 10 = 12; feeds P^2, P*PP
   F R = fsub_lz<F, 2 * M, L2>(S2, acc.y);                     // < 2 + 5 = 7;   feeds R^2, R*T
   if (fis_zero_modp<F, M + XB + 1>(P)) {                      // P == +-Q: rare, out of line
@@ -132,32 +124,6 @@ CTT_HD void xyzz_madd_flag(XYZZ<F>& acc, bool& empty, const F& qx, const F& qy_i
     acc.zzz = F::mul(acc.zzz, PPP);
     return;
   }
-#if defined(CTT_MADD_SERIAL) && defined(__HIP_DEVICE_COMPILE__)
-  // experiment (profiles/accum_three_waves_r04.txt): one product at a time, in the order that keeps the fewest values alive,
-  // with scheduling barriers so that hipcc does not interleave them again
-#define CTT_SB() __builtin_amdgcn_sched_barrier(0)
-  CTT_SB();
-  F PP = F::sqr(P);
-  CTT_SB();
-  F RR = F::sqr(R);
-  CTT_SB();
-  F PPP = F::mul(P, PP);
-  CTT_SB();
-  F Q = F::mul(acc.x, PP);
-  CTT_SB();
-  F X3 = fsub3<F, 7>(RR, PPP, Q);
-  F T = fsub_lz<F, XB, L1>(Q, X3);
-  CTT_SB();
-  F Y3 = fmul_sub_lz<F, 2 * M, L1>(R, T, acc.y, PPP);
-  CTT_SB();
-  acc.x = X3;
-  acc.y = Y3;
-  acc.zz = F::mul(acc.zz, PP);
-  CTT_SB();
-  acc.zzz = F::mul(acc.zzz, PPP);
-  CTT_SB();
-#undef CTT_SB
-#else
   F PP, RR, PPP, Q;
   fsqr_pair<F>(P, R, PP, RR);                                 // 144, 49   (121, 36 when P, R are normalised: < 128)
   fmul_pair<F>(P, PP, acc.x, PP, PPP, Q);                     // 24, 18
@@ -170,7 +136,6 @@ CTT_HD void xyzz_madd_flag(XYZZ<F>& acc, bool& empty, const F& qx, const F& qy_i
   fmul_pair<F>(acc.zz, PP, acc.zzz, PPP, Z2, Z3);
   acc.zz = Z2;
   acc.zzz = Z3;
-#endif
 }
 
 // The same addition with the accumulator held as separate X, Y and a ZZ/ZZZ holder (get / put) -- the form the accumulate

@@ -685,11 +685,7 @@ template <class F, int B, bool LZ> CTT_HD F fmul_sub_lz(const F& a, const F& b, 
 }
 // two independent products / squares: interleaved where the field supports it (fpu.h mul_pair)
 template <class F> CTT_HD void fmul_pair(const F& a, const F& b, const F& c, const F& d, F& r1, F& r2) {
-#if defined(CTT_FPU_NO_PAIRS)   // experiment: one product at a time (fewer live registers: profiles/accum_three_waves_r04.txt)
-  if constexpr (false) {
-#else
   if constexpr (F::UNSAT) {
-#endif
     F::mul_pair(a, b, c, d, r1, r2);
   } else {
     r1 = F::mul(a, b);
@@ -697,11 +693,7 @@ template <class F> CTT_HD void fmul_pair(const F& a, const F& b, const F& c, con
   }
 }
 template <class F> CTT_HD void fsqr_pair(const F& a, const F& c, F& r1, F& r2) {
-#if defined(CTT_FPU_NO_PAIRS)
-  if constexpr (false) {
-#else
   if constexpr (F::UNSAT) {
-#endif
     F::sqr_pair(a, c, r1, r2);
   } else {
     r1 = F::sqr(a);
