@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTT_MSM_HIP_LIB") or os.path.join(HERE, "libctt_msm_hip.so")
 
 _lib = None
-ABI_VERSION = 6  # ctt_hip_msm_abi_version() of the library this package was written against
+ABI_VERSION = 7  # ctt_hip_msm_abi_version() of the library this package was written against
 
 
 class HipLibraryMissing(RuntimeError):
@@ -31,7 +31,12 @@ def exported_symbols():
              "ctt_hip_msm_with_bases", "ctt_hip_msm_with_bases_submit", "ctt_hip_msm_bases_create_table", "ctt_hip_msm_bases_window_bits", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
              "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream", "ctt_hip_msm_wait_stream",
              "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min", "ctt_hip_subgroup_check", "ctt_hip_fr_quotient",
-             "ctt_hip_msm_host", "ctt_hip_msm_available"]
+             "ctt_hip_msm_host", "ctt_hip_msm_available",
+             # part 3: the MSM's callers under the reference's names + their host-only pieces
+             "ctt_eth_kzg_context_new", "ctt_eth_kzg_context_delete", "ctt_eth_kzg_blob_to_kzg_commitment", "ctt_eth_kzg_compute_kzg_proof",
+             "ctt_eth_kzg_compute_blob_kzg_proof", "ctt_eth_evm_bls12381_g1msm", "ctt_eth_evm_bls12381_g2msm",
+             "ctt_hip_eth_kzg_context_from_srs", "ctt_hip_sha256", "ctt_hip_bls12_381_g1_decompress", "ctt_hip_bls12_381_g1_compress",
+             "ctt_hip_eth_kzg_blob_to_scalars", "ctt_hip_eth_kzg_challenge", "ctt_hip_eth_kzg_quotient_host"]
     return syms
 
 
@@ -96,6 +101,35 @@ def lib():
         L.ctt_hip_msm_host.restype = i32
         L.ctt_hip_msm_available.argtypes = []
         L.ctt_hip_msm_available.restype = i32
+    if "ctt_eth_kzg_context_new" not in missing:
+        u8 = ctypes.c_uint8   # the reference's status enums are __attribute__((__packed__)): one byte
+        L.ctt_eth_kzg_context_new.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, u8]
+        L.ctt_eth_kzg_context_new.restype = u8
+        L.ctt_eth_kzg_context_delete.argtypes = [vp]
+        L.ctt_eth_kzg_context_delete.restype = None
+        L.ctt_eth_kzg_blob_to_kzg_commitment.argtypes = [vp, vp, vp]
+        L.ctt_eth_kzg_blob_to_kzg_commitment.restype = u8
+        L.ctt_eth_kzg_compute_kzg_proof.argtypes = [vp, vp, vp, vp, vp]
+        L.ctt_eth_kzg_compute_kzg_proof.restype = u8
+        L.ctt_eth_kzg_compute_blob_kzg_proof.argtypes = [vp, vp, vp, vp]
+        L.ctt_eth_kzg_compute_blob_kzg_proof.restype = u8
+        for nm in ("ctt_eth_evm_bls12381_g1msm", "ctt_eth_evm_bls12381_g2msm"):
+            getattr(L, nm).argtypes = [vp, sz, vp, sz]
+            getattr(L, nm).restype = u8
+        L.ctt_hip_eth_kzg_context_from_srs.argtypes = [ctypes.POINTER(vp), vp, sz, i32, i32]
+        L.ctt_hip_eth_kzg_context_from_srs.restype = i32
+        L.ctt_hip_sha256.argtypes = [vp, vp, sz]
+        L.ctt_hip_sha256.restype = None
+        L.ctt_hip_bls12_381_g1_decompress.argtypes = [vp, vp]
+        L.ctt_hip_bls12_381_g1_decompress.restype = i32
+        L.ctt_hip_bls12_381_g1_compress.argtypes = [vp, vp]
+        L.ctt_hip_bls12_381_g1_compress.restype = None
+        L.ctt_hip_eth_kzg_blob_to_scalars.argtypes = [vp, vp]
+        L.ctt_hip_eth_kzg_blob_to_scalars.restype = i32
+        L.ctt_hip_eth_kzg_challenge.argtypes = [vp, vp, vp]
+        L.ctt_hip_eth_kzg_challenge.restype = None
+        L.ctt_hip_eth_kzg_quotient_host.argtypes = [vp, vp, vp, vp]
+        L.ctt_hip_eth_kzg_quotient_host.restype = None
     L.ctt_hip_sum_reduce.argtypes = [vp, i32, i32, vp, vp, sz, i32]
     L.ctt_hip_sum_reduce.restype = i32
     L.ctt_hip_batch_affine.argtypes = [vp, i32, i32, vp, vp, sz, i32]

@@ -1,0 +1,741 @@
+// protocols.hip -- the MSM's immediate callers behind the reference's own C symbols:
+//
+//   EIP-4844 KZG    ctt_eth_kzg_blob_to_kzg_commitment / _compute_kzg_proof / _compute_blob_kzg_proof and the context
+//                   constructor / destructor   (include/constantine/protocols/ethereum_eip4844_kzg.h:106,126,153,200,238;
+//                   constantine/ethereum_eip4844_kzg.nim:297-444, commitments/kzg.nim:186-223)
+//   EIP-2537        ctt_eth_evm_bls12381_g1msm / _g2msm   (include/constantine/protocols/ethereum_evm_precompiles.h:386,419;
+//                   constantine/ethereum_evm_precompiles.nim:316-389,894-1060)
+//
+// Host side in C++: wire formats, range / curve checks, the Fiat-Shamir hash, point (de)compression.  GPU side: every MSM
+// (cached SRS: ctt_hip_msm_with_bases; precompile inputs: ctt_hip_msm_host), the subgroup checks (ctt_hip_subgroup_check) and
+// the quotient polynomial of an opening (ctt_hip_fr_quotient; the branch "z is a root of unity" runs the reference's other
+// formula here on the host).  Verification needs pairings and is out of scope, like the PeerDAS cell functions.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "host_fp64.h"
+
+// (part 3 of the header declares this file's symbols with the reference's packed enums and byte-array structs; the definitions
+// below spell the same ABI with uint8_t and plain pointers, so the typed declarations stay out of this translation unit)
+#define CTT_MSM_HIP_NO_PROTOCOLS 1
+#include "../../include/ctt_msm_hip.h"
+
+using namespace ctt;
+
+namespace {
+
+using FpH = Fp64<BLS12_381_Fp>;
+using FrH = Fp64<BLS12_381_Fr>;
+using Fp2H = Fp2<FpH>;
+constexpr int N_BLOB = 4096;
+
+#define PROT_HIP_CHECK(x)                                                                                          \
+  do {                                                                                                             \
+    hipError_t e_ = (x);                                                                                           \
+    if (e_ != hipSuccess) {                                                                                        \
+      fprintf(stderr, "[ctt_msm_hip] FATAL: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+      abort();                                                                                                     \
+    }                                                                                                              \
+  } while (0)
+
+// ---- field helpers (host, 64-bit limbs) ---------------------------------------------------------------------------------
+template <class F>
+F raw_const(const uint32_t* w) {
+  F r;
+  for (int i = 0; i < F::N; i++) r.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+  return r;
+}
+// canonical little-endian limbs < modulus?
+template <class F>
+bool below_modulus(const uint64_t* v) {
+  for (int i = F::N - 1; i >= 0; i--) {
+    if (v[i] < F::P(i)) return true;
+    if (v[i] > F::P(i)) return false;
+  }
+  return false;  // equal
+}
+// big-endian bytes (8*N of them) -> canonical limbs
+template <class F>
+void limbs_from_be(const uint8_t* be, uint64_t* v) {
+  for (int i = 0; i < F::N; i++) {
+    uint64_t w = 0;
+    for (int b = 0; b < 8; b++) w = (w << 8) | be[8 * (F::N - 1 - i) + b];
+    v[i] = w;
+  }
+}
+template <class F>
+void limbs_to_be(const uint64_t* v, uint8_t* be) {
+  for (int i = 0; i < F::N; i++)
+    for (int b = 0; b < 8; b++) be[8 * (F::N - 1 - i) + b] = (uint8_t)(v[i] >> (56 - 8 * b));
+}
+template <class F>
+F to_mont(const uint64_t* canon) {
+  F a;
+  for (int i = 0; i < F::N; i++) a.l[i] = canon[i];
+  return F::mul(a, raw_const<F>(F::Params::R2));
+}
+template <class F>
+void from_mont(const F& a, uint64_t* canon) {
+  F one_raw = F::zero();
+  one_raw.l[0] = 1;
+  const F r = F::mul(a, one_raw);
+  for (int i = 0; i < F::N; i++) canon[i] = r.l[i];
+}
+template <class F>
+F fpow(const F& base, const uint64_t* e, int nlimbs) {
+  F r = F::one();
+  bool started = false;
+  for (int i = nlimbs * 64 - 1; i >= 0; i--) {
+    if (started) r = F::sqr(r);
+    if ((e[i >> 6] >> (i & 63)) & 1) {
+      r = started ? F::mul(r, base) : base;
+      started = true;
+    }
+  }
+  return r;
+}
+// v > (p-1)/2 for a canonical value
+bool fp_is_larger_half(const uint64_t* v) {
+  uint64_t h[FpH::N];   // (p-1)/2
+  uint64_t carry = 0;
+  for (int i = FpH::N - 1; i >= 0; i--) {
+    const uint64_t w = FpH::P(i) - (i == 0 ? 1 : 0);   // p is odd: p - 1 only changes limb 0
+    h[i] = (w >> 1) | (carry << 63);
+    carry = w & 1;
+  }
+  for (int i = FpH::N - 1; i >= 0; i--) {
+    if (v[i] > h[i]) return true;
+    if (v[i] < h[i]) return false;
+  }
+  return false;
+}
+
+// ---- SHA-256 (FIPS 180-4), for the Fiat-Shamir challenge of compute_blob_kzg_proof -------------------------------------
+struct Sha256 {
+  uint32_t h[8];
+  uint8_t buf[64];
+  uint64_t len = 0;
+  size_t fill = 0;
+  Sha256() {
+    static const uint32_t iv[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    memcpy(h, iv, sizeof h);
+  }
+  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  void block(const uint8_t* p) {
+    static const uint32_t K[64] = {
+        0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu,
+        0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau,
+        0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u,
+        0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u,
+        0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu,
+        0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+      const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+      const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g);
+      const uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+      const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & b) ^ (a & c) ^ (b & c);
+      const uint32_t t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const uint8_t* p, size_t n) {
+    len += n;
+    while (n) {
+      if (fill == 0 && n >= 64) {
+        block(p);
+        p += 64;
+        n -= 64;
+        continue;
+      }
+      const size_t take = n < 64 - fill ? n : 64 - fill;
+      memcpy(buf + fill, p, take);
+      fill += take;
+      p += take;
+      n -= take;
+      if (fill == 64) {
+        block(buf);
+        fill = 0;
+      }
+    }
+  }
+  void finish(uint8_t out[32]) {
+    const uint64_t bits = len * 8;
+    const uint8_t one = 0x80, zero = 0;
+    update(&one, 1);
+    while (fill != 56) update(&zero, 1);
+    uint8_t lb[8];
+    for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+    update(lb, 8);
+    for (int i = 0; i < 8; i++) {
+      out[4 * i] = (uint8_t)(h[i] >> 24);
+      out[4 * i + 1] = (uint8_t)(h[i] >> 16);
+      out[4 * i + 2] = (uint8_t)(h[i] >> 8);
+      out[4 * i + 3] = (uint8_t)h[i];
+    }
+  }
+};
+
+// ---- status codes of the two reference interfaces (values as in their headers) -----------------------------------------
+enum : int { KZG_Success = 0, KZG_VerificationFailure = 1, KZG_InputsLengthsMismatch = 2, KZG_ScalarZero = 3, KZG_ScalarLargerThanCurveOrder = 4,
+             KZG_EccInvalidEncoding = 5, KZG_EccCoordinateGreaterThanOrEqualModulus = 6, KZG_EccPointNotOnCurve = 7, KZG_EccPointNotInSubgroup = 8 };
+enum : int { TS_Success = 0, TS_MissingOrInaccessibleFile = 1, TS_InvalidFile = 2 };
+enum : int { EVM_Success = 0, EVM_InvalidInputSize = 1, EVM_InvalidOutputSize = 2, EVM_IntLargerThanModulus = 3, EVM_PointNotOnCurve = 4,
+             EVM_PointNotInSubgroup = 5 };
+
+// ---- BLS12-381 G1, ZCash / IETF compressed encoding (serialization/codecs_bls12_381.nim) ---------------------------------
+// -> affine Montgomery {x, y} in the C-API layout (96 bytes; the neutral is (0,0)).  No subgroup check here.
+int g1_decompress(uint8_t aff[96], const uint8_t in[48]) {
+  if (!(in[0] & 0x80)) return KZG_EccInvalidEncoding;   // only the compressed form
+  if (in[0] & 0x40) {                                   // infinity: every other bit zero
+    if (in[0] & 0x3f) return KZG_EccInvalidEncoding;
+    for (int i = 1; i < 48; i++)
+      if (in[i]) return KZG_EccInvalidEncoding;
+    memset(aff, 0, 96);
+    return KZG_Success;
+  }
+  uint8_t xb[48];
+  memcpy(xb, in, 48);
+  xb[0] &= 0x1f;
+  uint64_t xc[FpH::N];
+  limbs_from_be<FpH>(xb, xc);
+  if (!below_modulus<FpH>(xc)) return KZG_EccCoordinateGreaterThanOrEqualModulus;
+  const FpH x = to_mont<FpH>(xc);
+  FpH four = FpH::one();
+  four = FpH::dbl(FpH::dbl(four));
+  const FpH y2 = FpH::add(FpH::mul(FpH::sqr(x), x), four);
+  // p = 3 (mod 4): y = y2^((p+1)/4)
+  uint64_t e[FpH::N];
+  {
+    uint64_t c = 1;   // p + 1
+    for (int i = 0; i < FpH::N; i++) {
+      const uint64_t s = FpH::P(i) + c;
+      c = (s < c) ? 1 : 0;
+      e[i] = s;
+    }
+    for (int i = 0; i < FpH::N; i++) e[i] = (e[i] >> 2) | (i + 1 < FpH::N ? e[i + 1] << 62 : 0);
+  }
+  FpH y = fpow<FpH>(y2, e, FpH::N);
+  if (!FpH::eq(FpH::sqr(y), y2)) return KZG_EccPointNotOnCurve;
+  uint64_t yc[FpH::N];
+  from_mont<FpH>(y, yc);
+  if (((in[0] & 0x20) != 0) != fp_is_larger_half(yc)) y = FpH::neg(y);
+  memcpy(aff, x.l, 48);
+  memcpy(aff + 48, y.l, 48);
+  return KZG_Success;
+}
+void g1_compress(uint8_t out[48], const uint8_t aff[96]) {
+  FpH x, y;
+  memcpy(x.l, aff, 48);
+  memcpy(y.l, aff + 48, 48);
+  if (x.is_zero() && y.is_zero()) {
+    memset(out, 0, 48);
+    out[0] = 0xc0;
+    return;
+  }
+  uint64_t xc[FpH::N], yc[FpH::N];
+  from_mont<FpH>(x, xc);
+  from_mont<FpH>(y, yc);
+  limbs_to_be<FpH>(xc, out);
+  out[0] |= 0x80 | (fp_is_larger_half(yc) ? 0x20 : 0);
+}
+
+// blob -> 4096 canonical little-endian scalars (blob_to_bigint_polynomial: every element < r)
+int blob_to_scalars(uint8_t* out_le, const uint8_t* blob) {
+  for (int i = 0; i < N_BLOB; i++) {
+    uint64_t v[FrH::N];
+    limbs_from_be<FrH>(blob + 32 * i, v);
+    if (!below_modulus<FrH>(v)) return KZG_ScalarLargerThanCurveOrder;
+    memcpy(out_le + 32 * i, v, 32);
+  }
+  return KZG_Success;
+}
+// 256-bit big-endian integer reduced mod r (fromDigest, ethereum_eip4844_kzg.nim:103-126; the EVM scalars, :941-952) -> canonical limbs
+void reduce_256_mod_r(const uint8_t be[32], uint64_t v[4]) {
+  limbs_from_be<FrH>(be, v);
+  while (!below_modulus<FrH>(v)) {   // 2^256 < 3r: at most two subtractions
+    uint64_t bw = 0;
+    for (int i = 0; i < 4; i++) {
+      const unsigned __int128 x = (unsigned __int128)v[i] - FrH::P(i) - bw;
+      v[i] = (uint64_t)x;
+      bw = (uint64_t)(x >> 64) & 1;
+    }
+  }
+}
+// fiatShamirChallenge (ethereum_eip4844_kzg.nim:126-148): sha256(domain | 16-byte big-endian degree | blob | commitment) mod r
+void fiat_shamir_challenge(uint64_t z[4], const uint8_t* blob, const uint8_t commitment[48]) {
+  Sha256 t;
+  t.update((const uint8_t*)"FSBLOBVERIFY_V1_", 16);
+  uint8_t deg[16] = {0};
+  deg[14] = (uint8_t)(N_BLOB >> 8);
+  deg[15] = (uint8_t)(N_BLOB & 0xff);
+  t.update(deg, 16);
+  t.update(blob, (size_t)N_BLOB * 32);
+  t.update(commitment, 48);
+  uint8_t d[32];
+  t.finish(d);
+  reduce_256_mod_r(d, z);
+}
+
+uint32_t bit_reverse(uint32_t i, int bits) {
+  uint32_t r = 0;
+  for (int b = 0; b < bits; b++) r |= ((i >> b) & 1u) << (bits - 1 - b);
+  return r;
+}
+
+// the 4096 roots of unity in bit-reversed order, Montgomery residues (ctx.domain_brp, commitments_setups/ethereum_kzg_srs.nim)
+std::vector<FrH> domain_brp() {
+  // w = 7^((r-1)/4096)
+  uint64_t e[4];
+  for (int i = 0; i < 4; i++) e[i] = FrH::P(i);
+  e[0] -= 1;
+  for (int i = 0; i < 4; i++) e[i] = (e[i] >> 12) | (i + 1 < 4 ? e[i + 1] << 52 : 0);
+  const uint64_t seven[4] = {7, 0, 0, 0};
+  const FrH w = fpow<FrH>(to_mont<FrH>(seven), e, 4);
+  std::vector<FrH> nat(N_BLOB), brp(N_BLOB);
+  FrH x = FrH::one();
+  for (int i = 0; i < N_BLOB; i++) {
+    nat[i] = x;
+    x = FrH::mul(x, w);
+  }
+  for (int i = 0; i < N_BLOB; i++) brp[i] = nat[bit_reverse((uint32_t)i, 12)];
+  return brp;
+}
+
+// Montgomery's trick: out[i] = 1/v[i]; every v[i] non-zero
+void batch_inverse(const std::vector<FrH>& v, std::vector<FrH>& out) {
+  const size_t n = v.size();
+  out.resize(n);
+  FrH run = FrH::one();
+  for (size_t i = 0; i < n; i++) {
+    out[i] = run;
+    run = FrH::mul(run, v[i]);
+  }
+  FrH inv = FrH::inv(run);
+  for (size_t i = n; i-- > 0;) {
+    out[i] = FrH::mul(inv, out[i]);
+    inv = FrH::mul(inv, v[i]);
+  }
+}
+
+// getQuotientPoly (math/polynomials/polynomials.nim; kzg_prove, commitments/kzg.nim:204-223) on the host: y = p(z) and
+// q = (p - y)/(X - z) in evaluation form over the bit-reversed domain, both branches (z outside / inside the domain).  The
+// device runs the first branch (ctt_hip_fr_quotient); this is what serves "z is a root of unity" and what the device form is
+// tested against.  poly, q: canonical little-endian scalars; z canonical limbs; y canonical limbs out.
+void quotient_host(const std::vector<FrH>& dom, const uint8_t* poly_le, const uint64_t z_c[4], uint8_t* q_le, uint64_t y_c[4]) {
+  const int n = N_BLOB;
+  std::vector<FrH> p(n);
+  for (int i = 0; i < n; i++) {
+    uint64_t v[4];
+    memcpy(v, poly_le + 32 * i, 32);
+    p[i] = to_mont<FrH>(v);
+  }
+  const FrH z = to_mont<FrH>(z_c);
+  int m = -1;
+  for (int i = 0; i < n; i++)
+    if (FrH::eq(dom[i], z)) {
+      m = i;
+      break;
+    }
+  std::vector<FrH> q(n), d, inv;
+  FrH y;
+  if (m < 0) {
+    d.resize(n);
+    for (int i = 0; i < n; i++) d[i] = FrH::sub(z, dom[i]);                       // z - w_i
+    batch_inverse(d, inv);
+    FrH s = FrH::zero();
+    for (int i = 0; i < n; i++) s = FrH::add(s, FrH::mul(FrH::mul(p[i], dom[i]), inv[i]));
+    const uint64_t nn[4] = {(uint64_t)n, 0, 0, 0};
+    const FrH zn = fpow<FrH>(z, nn, 1);                                          // z^n
+    const FrH ninv = FrH::inv(to_mont<FrH>(nn));
+    y = FrH::mul(FrH::mul(FrH::sub(zn, FrH::one()), ninv), s);                    // barycentric evaluation
+    for (int i = 0; i < n; i++) q[i] = FrH::mul(FrH::sub(y, p[i]), inv[i]);       // (p_i - y)/(w_i - z)
+  } else {
+    y = p[m];
+    d.reserve(n - 1);
+    for (int i = 0; i < n; i++)
+      if (i != m) d.push_back(FrH::sub(dom[i], z));                               // w_i - z
+    batch_inverse(d, inv);
+    const FrH zinv = FrH::inv(z);
+    FrH acc = FrH::zero();
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+      if (i == m) continue;
+      q[i] = FrH::mul(FrH::sub(p[i], y), inv[k++]);
+      acc = FrH::add(acc, FrH::mul(FrH::mul(q[i], dom[i]), zinv));                // q_m = - sum q_i w_i / z
+    }
+    q[m] = FrH::neg(acc);
+  }
+  from_mont<FrH>(y, y_c);
+  for (int i = 0; i < n; i++) {
+    uint64_t v[4];
+    from_mont<FrH>(q[i], v);
+    memcpy(q_le + 32 * i, v, 32);
+  }
+}
+
+}  // namespace
+
+// ---- the KZG context: the Lagrange SRS in bit-reversal order cached on the GPU, the domain next to it ---------------------
+struct ctt_eth_kzg_context_struct {
+  std::mutex mu;
+  ctt_hip_msm_ctx* hip = nullptr;
+  bool own_hip = false;
+  int device = 0;
+  ctt_hip_msm_bases* bases = nullptr;
+  std::vector<FrH> domain;      // bit-reversed roots of unity, Montgomery
+  void* d_domain = nullptr;     // the same on the device (ctt_hip_fr_quotient's layout)
+  void* d_poly = nullptr;       // 4096 canonical scalars of the blob being opened
+  void* d_q = nullptr;          // quotient evaluations (never leave the GPU before the MSM)
+};
+
+namespace {
+
+// srs: 4096 x 48 compressed G1 Lagrange points in ceremony (file) order
+int kzg_context_build(ctt_eth_kzg_context_struct** out, const uint8_t* srs, int device, int table) {
+  std::vector<uint8_t> aff((size_t)N_BLOB * 96);
+  std::vector<int> status(N_BLOB, 0);
+  // 4096 square roots (380 squarings each): a few host threads
+  const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nth; t++)
+    th.emplace_back([&, t]() {
+      for (int i = (int)t; i < N_BLOB; i += (int)nth)   // the commitment uses the points in bit-reversal order
+        status[i] = g1_decompress(aff.data() + (size_t)bit_reverse((uint32_t)i, 12) * 96, srs + (size_t)i * 48);
+    });
+  for (std::thread& x : th) x.join();
+  for (int i = 0; i < N_BLOB; i++)
+    if (status[i] != KZG_Success) return TS_InvalidFile;
+  ctt_eth_kzg_context_struct* c = new ctt_eth_kzg_context_struct();
+  c->device = device;
+  c->hip = ctt_hip_msm_ctx_create(device);
+  c->own_hip = true;
+  std::vector<uint8_t> ok(N_BLOB);
+  if (ctt_hip_subgroup_check(c->hip, CTT_HIP_BLS12_381_G1, ok.data(), aff.data(), N_BLOB, 0) != 0) {
+    ctt_hip_msm_ctx_destroy(c->hip);
+    delete c;
+    return TS_InvalidFile;
+  }
+  for (int i = 0; i < N_BLOB; i++)
+    if (!ok[i]) {
+      ctt_hip_msm_ctx_destroy(c->hip);
+      delete c;
+      return TS_InvalidFile;
+    }
+  c->bases = table ? ctt_hip_msm_bases_create_table(c->hip, CTT_HIP_BLS12_381_G1, aff.data(), N_BLOB, 0, 0)
+                   : ctt_hip_msm_bases_create(c->hip, CTT_HIP_BLS12_381_G1, aff.data(), N_BLOB, 0);
+  if (!c->bases) {
+    ctt_hip_msm_ctx_destroy(c->hip);
+    delete c;
+    return TS_InvalidFile;
+  }
+  c->domain = domain_brp();
+  PROT_HIP_CHECK(hipSetDevice(device));
+  PROT_HIP_CHECK(hipMalloc(&c->d_domain, (size_t)N_BLOB * 32));
+  PROT_HIP_CHECK(hipMalloc(&c->d_poly, (size_t)N_BLOB * 32));
+  PROT_HIP_CHECK(hipMalloc(&c->d_q, (size_t)N_BLOB * 32));
+  PROT_HIP_CHECK(hipMemcpy(c->d_domain, c->domain.data(), (size_t)N_BLOB * 32, hipMemcpyHostToDevice));
+  *out = c;
+  return TS_Success;
+}
+
+// [proof]_1 and y = p(z) for a validated polynomial (canonical scalars) and challenge
+void kzg_prove(ctt_eth_kzg_context_struct* c, uint8_t proof[48], uint64_t y_c[4], const uint8_t* poly_le, const uint64_t z_c[4]) {
+  std::lock_guard<std::mutex> lock(c->mu);
+  PROT_HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)ctt_hip_msm_stream(c->hip);
+  PROT_HIP_CHECK(hipMemcpyAsync(c->d_poly, poly_le, (size_t)N_BLOB * 32, hipMemcpyHostToDevice, s));
+  uint8_t r_aff[96];
+  const int rc = ctt_hip_fr_quotient(c->hip, CTT_HIP_BLS12_381_G1, c->d_q, y_c, c->d_poly, c->d_domain, z_c, N_BLOB);
+  int mrc;
+  if (rc == 0) {
+    mrc = ctt_hip_msm_with_bases(c->hip, c->bases, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, c->d_q, N_BLOB, 1);
+  } else if (rc == -2) {   // z is one of the roots of unity: the reference's other formula, on the host
+    std::vector<uint8_t> q((size_t)N_BLOB * 32);
+    quotient_host(c->domain, poly_le, z_c, q.data(), y_c);
+    mrc = ctt_hip_msm_with_bases(c->hip, c->bases, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, q.data(), N_BLOB, 0);
+  } else {
+    fprintf(stderr, "[ctt_msm_hip] FATAL: ctt_hip_fr_quotient failed (%d)\n", rc);
+    abort();
+  }
+  if (mrc != 0) {
+    fprintf(stderr, "[ctt_msm_hip] FATAL: the proof's MSM was refused (%d)\n", mrc);
+    abort();
+  }
+  g1_compress(proof, r_aff);
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+// ---- host-only helpers (no GPU): what tests/ check against the spec restatement, and what a binding may reuse -------------
+void ctt_hip_sha256(uint8_t out[32], const uint8_t* data, size_t len) {
+  Sha256 t;
+  t.update(data, len);
+  t.finish(out);
+}
+// -> ctt_eth_kzg_status; aff = affine Montgomery {x, y} (C-API layout), (0,0) for the neutral; no subgroup check
+int ctt_hip_bls12_381_g1_decompress(uint8_t aff[96], const uint8_t in[48]) { return g1_decompress(aff, in); }
+void ctt_hip_bls12_381_g1_compress(uint8_t out[48], const uint8_t aff[96]) { g1_compress(out, aff); }
+// blob (131072 bytes) -> 4096 canonical little-endian scalars; -> ctt_eth_kzg_status
+int ctt_hip_eth_kzg_blob_to_scalars(uint8_t* scalars_le, const uint8_t* blob) { return blob_to_scalars(scalars_le, blob); }
+// Fiat-Shamir challenge of compute_blob_kzg_proof, 32 big-endian bytes
+void ctt_hip_eth_kzg_challenge(uint8_t z_be[32], const uint8_t* blob, const uint8_t commitment[48]) {
+  uint64_t z[4];
+  fiat_shamir_challenge(z, blob, commitment);
+  limbs_to_be<FrH>(z, z_be);
+}
+// quotient polynomial on the host, both branches: poly / q = 4096 canonical little-endian scalars, z / y = 32 little-endian bytes
+void ctt_hip_eth_kzg_quotient_host(uint8_t* q_le, uint8_t y_le[32], const uint8_t* poly_le, const uint8_t z_le[32]) {
+  static const std::vector<FrH> dom = domain_brp();
+  uint64_t z[4], y[4];
+  memcpy(z, z_le, 32);
+  quotient_host(dom, poly_le, z, q_le, y);
+  memcpy(y_le, y, 32);
+}
+
+// ---- context (ethereum_eip4844_kzg.h:200-238) -------------------------------------------------------------------------
+// From memory: the 4096 x 48 bytes of the Lagrange-form G1 SRS in ceremony order (what the file's first 4096 lines hold).
+// device: the GPU the SRS is cached on; table != 0 caches it as a window table (ctt_hip_msm_bases_create_table).
+// -> ctt_eth_trusted_setup_status
+int ctt_hip_eth_kzg_context_from_srs(ctt_eth_kzg_context_struct** ctx, const uint8_t* g1_lagrange_compressed, size_t n_points,
+                                     int device, int table) {
+  if (!ctx || !g1_lagrange_compressed || n_points != (size_t)N_BLOB) return TS_InvalidFile;
+  return kzg_context_build(ctx, g1_lagrange_compressed, device, table);
+}
+// The c-kzg text format of the Ethereum ceremony ("4096\n65\n", one hex point per line; the reference ships it as
+// constantine/commitments_setups/trusted_setup_ethereum_kzg4844_reference.dat): format must be cttEthTSFormat_ckzg4844 (0).
+uint8_t ctt_eth_kzg_context_new(ctt_eth_kzg_context_struct** ctx, const char* filepath, uint8_t format) {
+  if (!ctx || !filepath || format != 0) return TS_InvalidFile;
+  FILE* f = fopen(filepath, "rb");
+  if (!f) return TS_MissingOrInaccessibleFile;
+  std::vector<uint8_t> srs((size_t)N_BLOB * 48);
+  int n1 = 0, n2 = 0;
+  int st = TS_Success;
+  if (fscanf(f, "%d %d", &n1, &n2) != 2 || n1 != N_BLOB || n2 != 65) st = TS_InvalidFile;
+  for (int i = 0; st == TS_Success && i < N_BLOB; i++) {
+    char tok[128];
+    if (fscanf(f, "%127s", tok) != 1 || strlen(tok) != 96) {
+      st = TS_InvalidFile;
+      break;
+    }
+    for (int b = 0; b < 48; b++) {
+      unsigned v;
+      if (sscanf(tok + 2 * b, "%2x", &v) != 1) {
+        st = TS_InvalidFile;
+        break;
+      }
+      srs[(size_t)i * 48 + b] = (uint8_t)v;
+    }
+  }
+  fclose(f);
+  if (st != TS_Success) return (uint8_t)st;
+  const char* dv = getenv("CTT_HIP_DEVICE");
+  return (uint8_t)kzg_context_build(ctx, srs.data(), dv ? atoi(dv) : 0, 0);
+}
+void ctt_eth_kzg_context_delete(ctt_eth_kzg_context_struct* c) {
+  if (!c) return;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    PROT_HIP_CHECK(hipSetDevice(c->device));
+    ctt_hip_msm_sync(c->hip);
+    if (c->bases) ctt_hip_msm_bases_destroy(c->hip, c->bases);
+    if (c->d_domain) PROT_HIP_CHECK(hipFree(c->d_domain));
+    if (c->d_poly) PROT_HIP_CHECK(hipFree(c->d_poly));
+    if (c->d_q) PROT_HIP_CHECK(hipFree(c->d_q));
+    if (c->own_hip) ctt_hip_msm_ctx_destroy(c->hip);
+  }
+  delete c;
+}
+
+// ---- EIP-4844 (ethereum_eip4844_kzg.h:106,126,153) -----------------------------------------------------------------------
+uint8_t ctt_eth_kzg_blob_to_kzg_commitment(const ctt_eth_kzg_context_struct* ctx, uint8_t dst[48], const uint8_t* blob) {
+  ctt_eth_kzg_context_struct* c = const_cast<ctt_eth_kzg_context_struct*>(ctx);
+  std::vector<uint8_t> poly((size_t)N_BLOB * 32);
+  const int st = blob_to_scalars(poly.data(), blob);
+  if (st != KZG_Success) return (uint8_t)st;
+  uint8_t r_aff[96];
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    const int rc = ctt_hip_msm_with_bases(c->hip, c->bases, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, poly.data(), N_BLOB, 0);
+    if (rc != 0) {
+      fprintf(stderr, "[ctt_msm_hip] FATAL: the commitment's MSM was refused (%d)\n", rc);
+      abort();
+    }
+  }
+  g1_compress(dst, r_aff);
+  return KZG_Success;
+}
+
+uint8_t ctt_eth_kzg_compute_kzg_proof(const ctt_eth_kzg_context_struct* ctx, uint8_t proof[48], uint8_t y_be[32], const uint8_t* blob,
+                                      const uint8_t z_be[32]) {
+  ctt_eth_kzg_context_struct* c = const_cast<ctt_eth_kzg_context_struct*>(ctx);
+  uint64_t z[4], y[4];
+  limbs_from_be<FrH>(z_be, z);
+  if (!below_modulus<FrH>(z)) return KZG_ScalarLargerThanCurveOrder;   // bytes_to_bls_field (:158-166) comes first
+  std::vector<uint8_t> poly((size_t)N_BLOB * 32);
+  const int st = blob_to_scalars(poly.data(), blob);
+  if (st != KZG_Success) return (uint8_t)st;
+  kzg_prove(c, proof, y, poly.data(), z);
+  limbs_to_be<FrH>(y, y_be);
+  return KZG_Success;
+}
+
+uint8_t ctt_eth_kzg_compute_blob_kzg_proof(const ctt_eth_kzg_context_struct* ctx, uint8_t proof[48], const uint8_t* blob,
+                                           const uint8_t commitment[48]) {
+  ctt_eth_kzg_context_struct* c = const_cast<ctt_eth_kzg_context_struct*>(ctx);
+  // bytes_to_kzg_commitment: a validated point (encoding, range, on the curve, in the subgroup; the neutral is allowed)
+  uint8_t aff[96];
+  int st = g1_decompress(aff, commitment);
+  if (st != KZG_Success) return (uint8_t)st;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    uint8_t ok = 0;
+    if (ctt_hip_subgroup_check(c->hip, CTT_HIP_BLS12_381_G1, &ok, aff, 1, 0) != 0) abort();
+    if (!ok) return KZG_EccPointNotInSubgroup;
+  }
+  std::vector<uint8_t> poly((size_t)N_BLOB * 32);
+  st = blob_to_scalars(poly.data(), blob);
+  if (st != KZG_Success) return (uint8_t)st;
+  uint64_t z[4], y[4];
+  fiat_shamir_challenge(z, blob, commitment);
+  kzg_prove(c, proof, y, poly.data(), z);
+  return KZG_Success;
+}
+
+// ---- EIP-2537 BLS12_G1MSM / BLS12_G2MSM (ethereum_evm_precompiles.h:386,419) -------------------------------------------
+// parseRawUint: a 64-byte big-endian field element, top 16 bytes zero, below p
+static bool evm_fp(const uint8_t* b64, FpH& out) {
+  for (int i = 0; i < 16; i++)
+    if (b64[i]) return false;
+  uint64_t v[FpH::N];
+  limbs_from_be<FpH>(b64 + 16, v);
+  if (!below_modulus<FpH>(v)) return false;
+  out = to_mont<FpH>(v);
+  return true;
+}
+static void evm_fp_out(const FpH& a, uint8_t* b64) {
+  uint64_t v[FpH::N];
+  from_mont<FpH>(a, v);
+  memset(b64, 0, 16);
+  limbs_to_be<FpH>(v, b64 + 16);
+}
+// The reference handles the pairs in order, each point fully (coordinates, curve, subgroup) before the next one
+// (fromRawCoords, ethereum_evm_precompiles.nim:316-389): the status is that of the FIRST offending pair.  parse[i] is the
+// host-side verdict on pair i; the subgroup checks of all points (or of those in front of the first offender) are one GPU launch.
+static int evm_validate(int curve, const uint8_t* pts, size_t aff_bytes, const std::vector<int>& parse) {
+  const size_t n = parse.size();
+  size_t bad = n;
+  for (size_t i = 0; i < n; i++)
+    if (parse[i] != EVM_Success) {
+      bad = i;
+      break;
+    }
+  if (bad > 0) {
+    std::vector<uint8_t> ok(bad);
+    if (ctt_hip_subgroup_check(nullptr, curve, ok.data(), pts, bad, 0) != 0) abort();
+    for (size_t i = 0; i < bad; i++)
+      if (!ok[i]) return EVM_PointNotInSubgroup;
+  }
+  (void)aff_bytes;
+  return bad == n ? EVM_Success : parse[bad];
+}
+static void evm_msm_or_die(int curve, void* r_aff, const void* coefs, const void* pts, size_t n) {
+  const int rc = ctt_hip_msm_host(curve, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, coefs, pts, n);
+  if (rc != 0) {
+    fprintf(stderr, "[ctt_msm_hip] FATAL: the precompile's MSM was refused (%d)\n", rc);
+    abort();
+  }
+}
+
+uint8_t ctt_eth_evm_bls12381_g1msm(uint8_t* r, size_t r_len, const uint8_t* inputs, size_t inputs_len) {
+  if (inputs_len == 0 || inputs_len % 160 != 0) return EVM_InvalidInputSize;
+  if (r_len != 128) return EVM_InvalidOutputSize;
+  const size_t n = inputs_len / 160;
+  std::vector<uint8_t> pts(n * 96, 0), coefs(n * 32);
+  std::vector<int> parse(n, EVM_Success);
+  FpH four = FpH::dbl(FpH::dbl(FpH::one()));
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t* rec = inputs + i * 160;
+    FpH x, y;
+    if (!evm_fp(rec, x) || !evm_fp(rec + 64, y)) {
+      parse[i] = EVM_IntLargerThanModulus;
+    } else if (!(x.is_zero() && y.is_zero())) {
+      if (!FpH::eq(FpH::sqr(y), FpH::add(FpH::mul(FpH::sqr(x), x), four))) parse[i] = EVM_PointNotOnCurve;
+      else {
+        memcpy(&pts[i * 96], x.l, 48);
+        memcpy(&pts[i * 96 + 48], y.l, 48);
+      }
+    }
+    uint64_t s[4];
+    reduce_256_mod_r(rec + 128, s);   // the spec allows any s < 2^256; the group is cyclic of order r
+    memcpy(&coefs[i * 32], s, 32);
+  }
+  const int st = evm_validate(CTT_HIP_BLS12_381_G1, pts.data(), 96, parse);
+  if (st != EVM_Success) return (uint8_t)st;
+  uint8_t aff[96];
+  evm_msm_or_die(CTT_HIP_BLS12_381_G1, aff, coefs.data(), pts.data(), n);
+  FpH x, y;
+  memcpy(x.l, aff, 48);
+  memcpy(y.l, aff + 48, 48);
+  evm_fp_out(x, r);         // the neutral is (0,0) in both encodings
+  evm_fp_out(y, r + 64);
+  return EVM_Success;
+}
+
+uint8_t ctt_eth_evm_bls12381_g2msm(uint8_t* r, size_t r_len, const uint8_t* inputs, size_t inputs_len) {
+  if (inputs_len == 0 || inputs_len % 288 != 0) return EVM_InvalidInputSize;
+  if (r_len != 256) return EVM_InvalidOutputSize;
+  const size_t n = inputs_len / 288;
+  std::vector<uint8_t> pts(n * 192, 0), coefs(n * 32);
+  std::vector<int> parse(n, EVM_Success);
+  const FpH four = FpH::dbl(FpH::dbl(FpH::one()));
+  const Fp2H b2{four, four};   // b' = 4 (1 + i)
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t* rec = inputs + i * 288;
+    Fp2H x, y;
+    if (!evm_fp(rec, x.c0) || !evm_fp(rec + 64, x.c1) || !evm_fp(rec + 128, y.c0) || !evm_fp(rec + 192, y.c1)) {
+      parse[i] = EVM_IntLargerThanModulus;
+    } else if (!(x.is_zero() && y.is_zero())) {
+      if (!Fp2H::eq(Fp2H::sqr(y), Fp2H::add(Fp2H::mul(Fp2H::sqr(x), x), b2))) parse[i] = EVM_PointNotOnCurve;
+      else {
+        memcpy(&pts[i * 192], x.c0.l, 48);
+        memcpy(&pts[i * 192 + 48], x.c1.l, 48);
+        memcpy(&pts[i * 192 + 96], y.c0.l, 48);
+        memcpy(&pts[i * 192 + 144], y.c1.l, 48);
+      }
+    }
+    uint64_t s[4];
+    reduce_256_mod_r(rec + 256, s);
+    memcpy(&coefs[i * 32], s, 32);
+  }
+  const int st = evm_validate(CTT_HIP_BLS12_381_G2, pts.data(), 192, parse);
+  if (st != EVM_Success) return (uint8_t)st;
+  uint8_t aff[192];
+  evm_msm_or_die(CTT_HIP_BLS12_381_G2, aff, coefs.data(), pts.data(), n);
+  for (int k = 0; k < 4; k++) {
+    FpH v;
+    memcpy(v.l, aff + 48 * k, 48);
+    evm_fp_out(v, r + 64 * k);
+  }
+  return EVM_Success;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

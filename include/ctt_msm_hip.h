@@ -261,6 +261,68 @@ int ctt_hip_fr_quotient(ctt_hip_msm_ctx* ctx, int curve, void* d_q, void* y, con
 /* the engine's hipStream_t */
 void* ctt_hip_msm_stream(ctt_hip_msm_ctx* ctx);
 
+/* ---- Part 3: the MSM's immediate callers under the reference's own names -----------------------
+ * EIP-4844 KZG commitments and opening proofs over a context that caches the Lagrange SRS on the GPU, and the EIP-2537
+ * BLS12_G1MSM / BLS12_G2MSM precompiles: same symbols, argument meaning and status enums as
+ *   include/constantine/protocols/ethereum_eip4844_kzg.h:106 (blob_to_kzg_commitment), :126 (compute_kzg_proof),
+ *       :153 (compute_blob_kzg_proof), :200 (context_new), :238 (context_delete)
+ *   include/constantine/protocols/ethereum_evm_precompiles.h:386 (g1msm), :419 (g2msm)
+ * (constantine/ethereum_eip4844_kzg.nim:297-444, constantine/ethereum_evm_precompiles.nim:894-1060).  Host side in C++
+ * (constantine_amd/csrc/protocols.hip), MSMs / subgroup checks / quotient polynomial on the GPU.  Verification (pairings), the
+ * PeerDAS cell functions and the other precompiles are out of scope and not exported.  There is no CPU fallback: a call the
+ * GPU cannot serve aborts with a message (these status enums have no member for it). */
+#ifndef CTT_MSM_HIP_NO_PROTOCOLS
+typedef uint8_t ctt_byte;   /* the reference's `byte` (constantine/core/datatypes.h) */
+typedef struct ctt_eth_kzg_context_struct ctt_eth_kzg_context;
+typedef struct { ctt_byte raw[48]; }        ctt_eth_kzg_commitment;
+typedef struct { ctt_byte raw[48]; }        ctt_eth_kzg_proof;
+typedef struct { ctt_byte raw[4096 * 32]; } ctt_eth_kzg_blob;
+typedef struct { ctt_byte raw[32]; }        ctt_eth_kzg_opening_challenge;
+typedef struct { ctt_byte raw[32]; }        ctt_eth_kzg_eval_at_challenge;
+typedef enum __attribute__((__packed__)) {
+  cttEthKzg_Success, cttEthKzg_VerificationFailure, cttEthKzg_InputsLengthsMismatch, cttEthKzg_ScalarZero,
+  cttEthKzg_ScalarLargerThanCurveOrder, cttEthKzg_EccInvalidEncoding, cttEthKzg_EccCoordinateGreaterThanOrEqualModulus,
+  cttEthKzg_EccPointNotOnCurve, cttEthKzg_EccPointNotInSubgroup, cttEthKzg_CellIndicesNotAscending,
+} ctt_eth_kzg_status;
+typedef enum __attribute__((__packed__)) {
+  cttEthTS_Success, cttEthTS_MissingOrInaccessibleFile, cttEthTS_InvalidFile
+} ctt_eth_trusted_setup_status;
+typedef enum __attribute__((__packed__)) { cttEthTSFormat_ckzg4844 } ctt_eth_trusted_setup_format;
+typedef enum __attribute__((__packed__)) {
+  cttEVM_Success, cttEVM_InvalidInputSize, cttEVM_InvalidOutputSize, cttEVM_IntLargerThanModulus, cttEVM_PointNotOnCurve,
+  cttEVM_PointNotInSubgroup, cttEVM_VerificationFailure,
+} ctt_evm_status;
+
+/* the c-kzg text format of the Ethereum ceremony; the SRS is cached on $CTT_HIP_DEVICE (default 0) */
+ctt_eth_trusted_setup_status ctt_eth_kzg_context_new(ctt_eth_kzg_context** ctx, const char* filepath,
+                                                     ctt_eth_trusted_setup_format format);
+void ctt_eth_kzg_context_delete(ctt_eth_kzg_context* ctx);
+ctt_eth_kzg_status ctt_eth_kzg_blob_to_kzg_commitment(const ctt_eth_kzg_context* ctx, ctt_eth_kzg_commitment* dst,
+                                                      const ctt_eth_kzg_blob* blob);
+ctt_eth_kzg_status ctt_eth_kzg_compute_kzg_proof(const ctt_eth_kzg_context* ctx, ctt_eth_kzg_proof* proof,
+                                                 ctt_eth_kzg_eval_at_challenge* y, const ctt_eth_kzg_blob* blob,
+                                                 const ctt_eth_kzg_opening_challenge* z);
+ctt_eth_kzg_status ctt_eth_kzg_compute_blob_kzg_proof(const ctt_eth_kzg_context* ctx, ctt_eth_kzg_proof* proof,
+                                                      const ctt_eth_kzg_blob* blob, const ctt_eth_kzg_commitment* commitment);
+ctt_evm_status ctt_eth_evm_bls12381_g1msm(ctt_byte* r, size_t r_len, const ctt_byte* inputs, size_t inputs_len);
+ctt_evm_status ctt_eth_evm_bls12381_g2msm(ctt_byte* r, size_t r_len, const ctt_byte* inputs, size_t inputs_len);
+
+/* Not in the reference: the context from memory -- the 4096 x 48 bytes of the Lagrange-form G1 SRS in ceremony (file) order --
+ * on a chosen GPU, optionally cached as a window table (ctt_hip_msm_bases_create_table).  -> ctt_eth_trusted_setup_status */
+int ctt_hip_eth_kzg_context_from_srs(ctt_eth_kzg_context** ctx, const uint8_t* g1_lagrange_compressed, size_t n_points,
+                                     int device, int table);
+/* Host-only pieces of the above (no GPU): SHA-256; BLS12-381 G1 compressed <-> affine Montgomery {x, y} (C-API layout, no
+ * subgroup check; -> ctt_eth_kzg_status); blob -> 4096 canonical little-endian scalars (-> ctt_eth_kzg_status); the Fiat-Shamir
+ * challenge of compute_blob_kzg_proof (32 big-endian bytes); the quotient polynomial of an opening on the host, both branches
+ * (4096 canonical little-endian scalars in and out, z and y 32 little-endian bytes). */
+void ctt_hip_sha256(uint8_t out[32], const uint8_t* data, size_t len);
+int ctt_hip_bls12_381_g1_decompress(uint8_t aff[96], const uint8_t in[48]);
+void ctt_hip_bls12_381_g1_compress(uint8_t out[48], const uint8_t aff[96]);
+int ctt_hip_eth_kzg_blob_to_scalars(uint8_t* scalars_le, const uint8_t* blob);
+void ctt_hip_eth_kzg_challenge(uint8_t z_be[32], const uint8_t* blob, const uint8_t commitment[48]);
+void ctt_hip_eth_kzg_quotient_host(uint8_t* q_le, uint8_t y_le[32], const uint8_t* poly_le, const uint8_t z_le[32]);
+#endif /* CTT_MSM_HIP_NO_PROTOCOLS */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,5 @@
-"""EIP-2537 G1MSM / G2MSM wire format (constantine_amd/evm.py) against the reference's pass and fail vectors
+"""EIP-2537 G1MSM / G2MSM: the reference's C symbols ctt_eth_evm_bls12381_g1msm / _g2msm (include/ctt_msm_hip.h part 3,
+csrc/protocols.hip; constantine_amd/evm.py is their ctypes caller) against the reference's pass and fail vectors
 (tests/protocol_ethereum_evm_precompiles/eip-2537/{,fail-}multiexp_G{1,2}_bls.json)."""
 import json
 import os
@@ -30,6 +31,13 @@ def test_malformed_inputs_are_rejected_on_the_host(group):
             fn(bytes.fromhex(inp))
         assert e.value.status.name == HOST_ONLY_ERRORS[err], name
     assert seen == 6
+    # the output buffer's length is part of the contract (ethereum_evm_precompiles.nim:925-929): checked after the input length
+    with pytest.raises(evm.EvmError) as e:
+        fn(bytes(160 if group == "g1" else 288), r_len=64)
+    assert e.value.status == evm.CttEVMStatus.cttEVM_InvalidOutputSize
+    with pytest.raises(evm.EvmError) as e:
+        fn(b"", r_len=64)
+    assert e.value.status == evm.CttEVMStatus.cttEVM_InvalidInputSize
 
 
 @pytest.mark.gpu

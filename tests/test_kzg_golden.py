@@ -63,21 +63,66 @@ def test_gpu_reproduces_commitments(setup):
         bases.close()
 
 
-# ---- the protocol-level caller (constantine_amd/kzg.py) -----------------------------------------------------
-def test_kzg_codec_and_validation_host_logic():
-    """Host logic of the KZG layer needs no GPU: point codec round trip, blob parsing, rejection of bad blobs."""
-    import os
-    from constantine_amd import kzg
+# ---- the protocol-level callers: the reference's C symbols (include/ctt_msm_hip.h part 3, csrc/protocols.hip) through
+# ---- constantine_amd/kzg.py; the spec restatement they are checked against is oracle/kzg_spec.py ------------------------------
+def test_spec_restatement_reproduces_the_reference_vectors():
+    """oracle/kzg_spec.py (the checker of the C++ host logic) is itself pinned: y = p(z) of every valid compute_kzg_proof vector
+    (incl. z = a root of unity and z = 0), the rejections decided before any MSM, and the codec on SRS points.  No GPU."""
+    from oracle import kzg_spec as ks
     raw = open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read()
     for i in (0, 1, 77, 4095):
         c = raw[48 * i:48 * i + 48]
-        P = kzg.deserialize_g1_compressed(c)
-        assert P == _golden.g1_decompress(c) and kzg.serialize_g1_compressed(P) == c
-    assert kzg.deserialize_g1_compressed(bytes([0xC0]) + bytes(47)) is None
-    with pytest.raises(kzg.KzgError):
-        kzg.deserialize_g1_compressed(bytes(48))            # compression flag missing
-    with pytest.raises(kzg.KzgError):
-        kzg.deserialize_g1_compressed(bytes([0x9F]) + bytes([0xFF]) * 47)   # x >= p
+        pt = ks.deserialize_g1_compressed(c)
+        assert pt == _golden.g1_decompress(c) and ks.serialize_g1_compressed(pt) == c
+    cases = _golden.kzg4844_proof_cases()["compute_kzg_proof"]
+    assert len(cases) == 52
+    seen_root = False
+    for case, blob, zb, res in cases:
+        if res is None:
+            with pytest.raises(ks.SpecError):
+                ks.bytes_to_bls_field(zb)
+                ks.blob_to_bigint_polynomial(blob)
+                raise AssertionError(case + ": neither z nor the blob was rejected")
+            continue
+        z = ks.bytes_to_bls_field(zb)
+        poly = [int.from_bytes(bytes(row), "little") for row in ks.blob_to_bigint_polynomial(blob)]
+        q, y = ks.quotient_polynomial(poly, z)
+        assert y.to_bytes(32, "big") == res[1], case
+        dom = ks.domain_brp()
+        seen_root |= z in dom
+        for i in (0, 1, 777, 4095):   # q really is (p - y) / (X - z) on the domain
+            assert q[i] * (dom[i] - z) % ks.R == (poly[i] - y) % ks.R or dom[i] == z, case
+    assert seen_root, "the vectors include openings at a root of unity"
+
+
+def test_host_logic_of_the_c_symbols():
+    """The host-only pieces of the protocol symbols (C++, no GPU): SHA-256 against hashlib, the G1 codec, blob parsing with the
+    reference's statuses, the Fiat-Shamir challenge and the quotient polynomial (both branches) against the spec restatement."""
+    import hashlib
+    import random
+    from constantine_amd import kzg
+    from oracle import kzg_spec as ks
+    rng = random.Random(5)
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 1000, 131072 + 64):
+        d = bytes(rng.randrange(256) for _ in range(n)) if n < 2000 else os.urandom(n)
+        assert kzg.sha256(d) == hashlib.sha256(d).digest(), n
+    raw = open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read()
+    for i in list(range(0, 4096, 97)) + [4095]:
+        c = raw[48 * i:48 * i + 48]
+        aff = kzg.g1_decompress(c)
+        assert aff == ks.aff_mont_bytes(_golden.g1_decompress(c)) and kzg.g1_compress(aff) == c
+    assert kzg.g1_decompress(bytes([0xC0]) + bytes(47)) == bytes(96) and kzg.g1_compress(bytes(96)) == bytes([0xC0]) + bytes(47)
+    for bad, want in ((bytes(48), "cttEthKzg_EccInvalidEncoding"),                                    # compression flag missing
+                      (bytes([0xE0]) + bytes(47), "cttEthKzg_EccInvalidEncoding"),                   # infinity with the sign bit
+                      (bytes([0xC0]) + bytes(46) + b"\x01", "cttEthKzg_EccInvalidEncoding"),         # infinity with payload
+                      (bytes([0x9F]) + bytes([0xFF]) * 47, "cttEthKzg_EccCoordinateGreaterThanOrEqualModulus"),
+                      (bytes([0x80]) + bytes(46) + b"\x02", "cttEthKzg_EccPointNotOnCurve")):         # x = 2: 12 is not a square
+        with pytest.raises(kzg.KzgError) as e:
+            kzg.g1_decompress(bad)
+        assert e.value.status.name == want, bad.hex()
+        with pytest.raises(ks.SpecError) as e2:
+            ks.deserialize_g1_compressed(bad)
+        assert e2.value.status == want
     n_bad = 0
     for name, blob, com in _golden.kzg4844_raw_cases():
         if com is None:
@@ -89,61 +134,60 @@ def test_kzg_codec_and_validation_host_logic():
             assert e.value.status == want, name
         else:
             poly = kzg.blob_to_bigint_polynomial(blob)
-            assert poly.shape == (4096, 32)
-            assert int.from_bytes(bytes(poly[5]), "little") == int.from_bytes(blob[160:192], "big")
+            assert bytes(poly) == bytes(ks.blob_to_bigint_polynomial(blob)), name
     assert n_bad == 4
+    cases = _golden.kzg4844_proof_cases()
+    for case, blob, com, res in cases["compute_blob_kzg_proof"]:
+        if len(blob) == kzg.BYTES_PER_BLOB and len(com) == 48:
+            assert int.from_bytes(kzg.compute_challenge(blob, com), "big") == ks.compute_challenge(blob, com), case
+    checked = roots = 0
+    for case, blob, zb, res in cases["compute_kzg_proof"]:
+        if res is None:
+            continue
+        z = int.from_bytes(zb, "big")
+        is_root = z in ks.domain_brp()
+        if not is_root and checked >= 6:
+            continue
+        poly_le = kzg.blob_to_bigint_polynomial(blob)
+        q, y = kzg.quotient_polynomial_host(poly_le, z)
+        assert y.to_bytes(32, "big") == res[1], case
+        want_q, want_y = ks.quotient_polynomial([int.from_bytes(bytes(r), "little") for r in poly_le], z)
+        assert y == want_y and [int.from_bytes(bytes(r), "little") for r in q] == want_q, case
+        checked += 1
+        roots += is_root
+    assert checked >= 7 and roots >= 1
 
 
 @pytest.mark.gpu
 def test_blob_to_kzg_commitment_on_gpu():
-    """blob_to_kzg_commitment (ethereum_eip4844_kzg.nim:297-330) over the GPU MSM: all reference vectors."""
-    import os
+    """ctt_eth_kzg_blob_to_kzg_commitment (ethereum_eip4844_kzg.h:106) over the GPU MSM: all 11 reference vectors, with the SRS
+    cached as plain records and as a window table."""
     from constantine_amd import kzg
     raw = open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read()
-    ctx = kzg.EthereumKZGContext(raw)
-    try:
-        for name, blob, com in _golden.kzg4844_raw_cases():
-            if com is None:
-                with pytest.raises(kzg.KzgError):
-                    kzg.blob_to_kzg_commitment(ctx, blob)
-            else:
-                assert kzg.blob_to_kzg_commitment(ctx, blob) == com, name
-    finally:
-        ctx.delete()
-
-
-# ---- proofs (compute_kzg_proof / compute_blob_kzg_proof) ---------------------------------------------------------
-def test_quotient_polynomial_evaluations_match_the_reference_vectors():
-    """Host part of kzg_prove: y = p(z) of every valid compute_kzg_proof vector (incl. z = a root of unity and z = 0),
-    and the rejections that are decided before any MSM (z >= r, malformed blob).  No GPU."""
-    from constantine_amd import kzg
-    cases = _golden.kzg4844_proof_cases()["compute_kzg_proof"]
-    seen_root = False
-    for case, blob, zb, res in cases:
-        if res is None:
-            with pytest.raises(kzg.KzgError):
-                z = kzg._bytes_to_bls_field(zb)
-                kzg.blob_to_bigint_polynomial(blob)
-                raise AssertionError(case + ": neither z nor the blob was rejected")
-            continue
-        z = kzg._bytes_to_bls_field(zb)
-        poly = [int.from_bytes(bytes(row), "little") for row in kzg.blob_to_bigint_polynomial(blob)]
-        q, y = kzg.quotient_polynomial(poly, z)
-        assert y.to_bytes(32, "big") == res[1], case
-        seen_root |= z in kzg._domain_brp()
-        # q really is (p - y) / (X - z) on the domain
-        dom = kzg._domain_brp()
-        for i in (0, 1, 777, 4095):
-            assert q[i] * (dom[i] - z) % kzg._R == (poly[i] - y) % kzg._R or dom[i] == z, case
-    assert seen_root, "the vectors include openings at a root of unity"
+    for table in (False, True):
+        ctx = kzg.EthereumKZGContext(raw, table=table)
+        try:
+            n = 0
+            for name, blob, com in _golden.kzg4844_raw_cases():
+                n += 1
+                if com is None:
+                    with pytest.raises(kzg.KzgError):
+                        kzg.blob_to_kzg_commitment(ctx, blob)
+                else:
+                    assert kzg.blob_to_kzg_commitment(ctx, blob) == com, name
+            assert n == 11
+        finally:
+            ctx.delete()
 
 
 @pytest.mark.gpu
 def test_compute_kzg_proof_vectors_on_gpu():
+    """ctt_eth_kzg_compute_kzg_proof / _compute_blob_kzg_proof (ethereum_eip4844_kzg.h:126,153): all 52 + 15 reference vectors."""
     from constantine_amd import kzg
     ctx = kzg.EthereumKZGContext(open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read())
     try:
         cases = _golden.kzg4844_proof_cases()
+        assert len(cases["compute_kzg_proof"]) == 52 and len(cases["compute_blob_kzg_proof"]) == 15
         for case, blob, zb, res in cases["compute_kzg_proof"]:
             if res is None:
                 with pytest.raises(kzg.KzgError):
@@ -160,19 +204,42 @@ def test_compute_kzg_proof_vectors_on_gpu():
         ctx.delete()
 
 
+@pytest.mark.gpu
+def test_kzg_context_from_the_ceremony_text_file(tmp_path):
+    """ctt_eth_kzg_context_new: the c-kzg text format ("4096\\n65\\n" + hex lines) written from the golden SRS; a missing file and
+    a malformed one give the reference's trusted-setup statuses."""
+    from constantine_amd import kzg
+    raw = open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read()
+    path = tmp_path / "setup.txt"
+    g2 = bytes([0xC0]) + bytes(95)   # the 65 G2 lines are not read by the commitment / proof functions
+    path.write_text("4096\n65\n" + "\n".join(raw[48 * i:48 * i + 48].hex() for i in range(4096)) + "\n" + "\n".join([g2.hex()] * 65) + "\n")
+    ctx = kzg.EthereumKZGContext.from_ckzg_text(path)
+    try:
+        name, blob, com = next(c for c in _golden.kzg4844_raw_cases() if c[2] is not None)
+        assert kzg.blob_to_kzg_commitment(ctx, blob) == com
+    finally:
+        ctx.delete()
+    with pytest.raises(ValueError, match="cttEthTS_MissingOrInaccessibleFile"):
+        kzg.EthereumKZGContext.from_ckzg_text(tmp_path / "nope.txt")
+    bad = tmp_path / "bad.txt"
+    bad.write_text("4096\n65\n" + raw[:48].hex() + "\nzz\n")
+    with pytest.raises(ValueError, match="cttEthTS_InvalidFile"):
+        kzg.EthereumKZGContext.from_ckzg_text(bad)
+
+
 def test_quotient_polynomial_bodies_match_the_host_formula():
-    """ctt_hip_fr_quotient's per-lane bodies (msm_bodies.h fr_quotient_*_body, run here by tests/emu) against the host formula
+    """ctt_hip_fr_quotient's per-lane bodies (msm_bodies.h fr_quotient_*_body, run here by tests/emu) against the spec formula
     quotient_polynomial: barycentric y = p(z) and q_i = (p_i - y)/(w_i - z) over the bit-reversed 4096-point domain, for several
     lane spans (one Montgomery-trick run and one inversion per lane)."""
     import random
 
-    from constantine_amd import kzg
+    from oracle import kzg_spec as ks
     from tests.emu import emu
-    r = kzg._R
-    n = kzg.FIELD_ELEMENTS_PER_BLOB
+    r = ks.R
+    n = ks.FIELD_ELEMENTS_PER_BLOB
     rng = random.Random(44)
-    dom = kzg._domain_brp()
-    R = 1 << 256
+    dom = ks.domain_brp()
+    R = ks.FR_MONT
     dom_m = np.frombuffer(b"".join((w * R % r).to_bytes(32, "little") for w in dom), dtype=np.uint8).reshape(n, 32)
     for K in (8, 5, 64):
         poly = [rng.randrange(r) for _ in range(n)]
@@ -180,7 +247,7 @@ def test_quotient_polynomial_bodies_match_the_host_formula():
         poly[7] = r - 1
         z = rng.randrange(r)
         assert pow(z, n, r) != 1
-        want_q, want_y = kzg.quotient_polynomial(poly, z)
+        want_q, want_y = ks.quotient_polynomial(poly, z)
         poly_le = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in poly), dtype=np.uint8).reshape(n, 32)
         scale = (pow(z, n, r) - 1) * pow(n, -1, r) % r
         q, y = emu.fr_quotient("bls12_381_g1", poly_le, dom_m, np.frombuffer((z * R % r).to_bytes(32, "little"), dtype=np.uint8),
@@ -191,24 +258,37 @@ def test_quotient_polynomial_bodies_match_the_host_formula():
 
 @pytest.mark.gpu
 def test_quotient_polynomial_on_device_matches_the_host_formula():
-    """The device path of the proofs (ctt_hip_fr_quotient) against quotient_polynomial, and the branch it leaves to the host
+    """The device path of the proofs (ctt_hip_fr_quotient) against the spec formula, and the branch it leaves to the host
     (z a root of unity: -2)."""
+    import ctypes
     import random
 
-    import os
-
-    from constantine_amd import kzg
-    ctx = kzg.EthereumKZGContext(open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read())
-    r = kzg._R
-    n = kzg.FIELD_ELEMENTS_PER_BLOB
+    import torch
+    from constantine_amd import _lib
+    from oracle import kzg_spec as ks
+    L = _lib.lib()
+    r = ks.R
+    n = ks.FIELD_ELEMENTS_PER_BLOB
     rng = random.Random(45)
+    dom = ks.domain_brp()
+    d_dom = torch.from_numpy(np.frombuffer(b"".join((w * ks.FR_MONT % r).to_bytes(32, "little") for w in dom), dtype=np.uint8).reshape(n, 32).copy()).cuda()
+    d_q = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+
+    def device_quotient(poly_le, z):
+        d_poly = torch.from_numpy(np.ascontiguousarray(poly_le)).cuda()
+        torch.cuda.synchronize()
+        y = np.zeros(32, dtype=np.uint8)
+        zb = np.frombuffer(z.to_bytes(32, "little"), dtype=np.uint8).copy()
+        rc = L.ctt_hip_fr_quotient(None, 0, ctypes.c_void_p(d_q.data_ptr()), y.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_poly.data_ptr()),
+                                   ctypes.c_void_p(d_dom.data_ptr()), zb.ctypes.data_as(ctypes.c_void_p), n)
+        return rc, int.from_bytes(bytes(y), "little")
+
     for _ in range(3):
         poly = [rng.randrange(r) for _ in range(n)]
         z = rng.randrange(r)
-        want_q, want_y = kzg.quotient_polynomial(poly, z)
+        want_q, want_y = ks.quotient_polynomial(poly, z)
         poly_le = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in poly), dtype=np.uint8).reshape(n, 32)
-        d_q, y = kzg.quotient_polynomial_device(ctx, poly_le, z)
-        assert y == want_y
+        rc, y = device_quotient(poly_le, z)
+        assert rc == 0 and y == want_y
         assert [int.from_bytes(bytes(row), "little") for row in d_q.cpu().numpy()] == want_q
-    assert kzg.quotient_polynomial_device(ctx, poly_le, kzg._domain_brp()[5]) is None
-    ctx.delete()
+    assert device_quotient(poly_le, dom[5])[0] == -2
