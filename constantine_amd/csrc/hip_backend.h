@@ -360,6 +360,12 @@ __global__ void __launch_bounds__(EC_BLOCK) k_fr_quotient_inv(FrQuotientArgs<Fr>
   fr_quotient_inv_body<Fr>(a, blockIdx.x * blockDim.x + threadIdx.x);
 }
 template <class Fr>
+__global__ void __launch_bounds__(FR_QUOTIENT_SUM_LANES) k_fr_quotient_sum(FrQuotientArgs<Fr> a) {
+  fr_quotient_sum_body<Fr>(a, threadIdx.x, FR_QUOTIENT_SUM_LANES);
+  __syncthreads();   // (orders the workgroup's global writes: one workgroup, the sums are read by its lane 0)
+  if (threadIdx.x == 0) fr_quotient_y_body<Fr>(a, FR_QUOTIENT_SUM_LANES);
+}
+template <class Fr>
 __global__ void __launch_bounds__(256) k_fr_quotient_out(FrQuotientArgs<Fr> a) {
   fr_quotient_out_body<Fr>(a, blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -505,8 +511,41 @@ struct HipBackend {
   }
   void d2h_async(int slot, void* dst_pinned, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst_pinned, src, b, hipMemcpyDeviceToHost, cur()));
-    HIP_CHECK(hipEventRecord(ev_done[slot], cur()));
+    if (!capturing) HIP_CHECK(hipEventRecord(ev_done[slot], cur()));   // (a captured MSM records it behind the graph launch)
   }
+  // ---- HIP graph of one lone MSM (MsmEngine::submit): the ~35 launches of a small MSM captured once per (inputs, plan) and
+  // replayed with one hipGraphLaunch.  Only for a caller that does not keep MSMs in flight (no tail stream inside a capture).
+  bool capturing = false;
+  bool graph_supported() const {
+    static const bool on = !(getenv("CTT_HIP_MSM_GRAPH") && atoi(getenv("CTT_HIP_MSM_GRAPH")) == 0);
+    return on && !timing;
+  }
+  void graph_begin() {
+    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    capturing = true;
+  }
+  // -> the instantiated graph (nullptr when the capture failed: the caller runs the MSM the ordinary way)
+  void* graph_end() {
+    hipGraph_t g = nullptr;
+    capturing = false;
+    if (hipStreamEndCapture(stream, &g) != hipSuccess || !g) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    HIP_CHECK(hipGraphDestroy(g));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    return (void*)ex;
+  }
+  void graph_launch(void* ex, int slot) {
+    HIP_CHECK(hipGraphLaunch((hipGraphExec_t)ex, stream));
+    HIP_CHECK(hipEventRecord(ev_done[slot], stream));
+  }
+  void graph_destroy(void* ex) { HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)ex)); }
   void d2h_wait(int slot) { HIP_CHECK(hipEventSynchronize(ev_done[slot])); }
   void d2h_sync(void* dst, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, stream));
@@ -821,8 +860,11 @@ struct CurveImpl {
     a.partial = a.inv + (size_t)n * Fr::N;
     a.q = (uint32_t*)d_q;
     a.y = a.partial + (size_t)((n + a.K - 1) / a.K) * Fr::N;
+    a.tsum = a.y + Fr::N;
     const uint32_t lanes = (n + a.K - 1) / a.K;
     hipLaunchKernelGGL(k_fr_quotient_inv<Fr>, dim3((lanes + EC_BLOCK - 1) / EC_BLOCK), dim3(EC_BLOCK), 0, bk->stream, a);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_fr_quotient_sum<Fr>, dim3(1), dim3(FR_QUOTIENT_SUM_LANES), 0, bk->stream, a);
     HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_fr_quotient_out<Fr>, dim3((n + 255) / 256), dim3(256), 0, bk->stream, a);
     HIP_CHECK(hipGetLastError());

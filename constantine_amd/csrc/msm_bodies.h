@@ -730,6 +730,7 @@ CTT_HD void batch_affine_body(const BatchAffineArgs<F>& a, uint32_t lane) {
 // did this in host Python integers: 4 ms next to a 0.36 ms MSM.  poly: canonical scalars as the MSM takes them; dom, z, inv:
 // Montgomery residues; partial / q / y: canonical (a Montgomery product of a canonical and a Montgomery factor is canonical).
 // ---------------------------------------------------------------------------------------------
+static constexpr uint32_t FR_QUOTIENT_SUM_LANES = 256;   // lanes of the one workgroup that adds up the lane sums
 template <class Fr>
 struct FrQuotientArgs {
   const uint32_t* poly;   // [n][Fr::N]  p_i, canonical
@@ -739,6 +740,7 @@ struct FrQuotientArgs {
   uint32_t n, K;          // elements; elements per lane of the first pass
   uint32_t* inv;          // [n][Fr::N]  1 / (z - w_i), Montgomery                      (pass 1 -> pass 2)
   uint32_t* partial;      // [ceil(n/K)][Fr::N]  per-lane sums of p_i w_i / (z - w_i), canonical
+  uint32_t* tsum;         // [FR_QUOTIENT_SUM_LANES][Fr::N]  strided sums of `partial` (fr_quotient_sum_body)
   uint32_t* q;            // [n][Fr::N]  out: quotient evaluations, canonical
   uint32_t* y;            // [Fr::N]     out: p(z), canonical
 };
@@ -776,15 +778,27 @@ CTT_HD void fr_quotient_inv_body(const FrQuotientArgs<Fr>& a, uint32_t lane) {
   }
   fr_store<Fr>(a.partial, lane, sum);
 }
-// pass 2, element i: y from the lane sums (every lane computes the same y), q_i = (y - p_i) / (z - w_i)
+// between the passes, ONE workgroup of T lanes: lane t adds up the lane sums t, t + T, ... into tsum[t] ...
+template <class Fr>
+CTT_HD void fr_quotient_sum_body(const FrQuotientArgs<Fr>& a, uint32_t t, uint32_t T) {
+  const uint32_t lanes = (a.n + a.K - 1) / a.K;
+  Fr s = Fr::zero();
+  for (uint32_t l = t; l < lanes; l += T) s = Fr::add(s, fr_load<Fr>(a.partial, l));
+  fr_store<Fr>(a.tsum, t, s);
+}
+// ... and (after a workgroup barrier) one lane adds the T sums: y = scale * sum.  (Round 3 had every one of the n lanes of
+// pass 2 re-sum all n/K lane sums: O(n^2/K) additions and loads -- nothing at the KZG size 4096, 1.4e11 additions at 2^20.)
+template <class Fr>
+CTT_HD void fr_quotient_y_body(const FrQuotientArgs<Fr>& a, uint32_t T) {
+  Fr s = Fr::zero();
+  for (uint32_t t = 0; t < T; t++) s = Fr::add(s, fr_load<Fr>(a.tsum, t));
+  fr_store<Fr>(a.y, 0, Fr::mul(s, a.scale));           // canonical
+}
+// pass 2, element i: q_i = (y - p_i) / (z - w_i)
 template <class Fr>
 CTT_HD void fr_quotient_out_body(const FrQuotientArgs<Fr>& a, uint32_t i) {
   if (i >= a.n) return;
-  const uint32_t lanes = (a.n + a.K - 1) / a.K;
-  Fr s = Fr::zero();
-  for (uint32_t l = 0; l < lanes; l++) s = Fr::add(s, fr_load<Fr>(a.partial, l));
-  const Fr y = Fr::mul(s, a.scale);                   // canonical
-  if (i == 0) fr_store<Fr>(a.y, 0, y);
+  const Fr y = fr_load<Fr>(a.y, 0);
   fr_store<Fr>(a.q, i, Fr::mul(Fr::sub(y, fr_load<Fr>(a.poly, i)), fr_load<Fr>(a.inv, i)));
 }
 

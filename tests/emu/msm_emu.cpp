@@ -26,6 +26,12 @@ struct EmuBackend {
   void free_host(void* p) { ::free(p); }
   void d2h_async(int, void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void d2h_wait(int) {}
+  // (HIP graphs of lone MSMs are a device matter: hip_backend.h)
+  bool graph_supported() const { return false; }
+  void graph_begin() {}
+  void* graph_end() { return nullptr; }
+  void graph_launch(void*, int) {}
+  void graph_destroy(void*) {}
   void tail_begin() {}
   void tail_end() {}
   void tail_wait() {}
@@ -319,7 +325,7 @@ struct EmuCurve {
                           void* q, void* y) {
     using Fr = typename C::Fr;
     const uint32_t lanes = (n + K - 1) / K;
-    std::vector<uint32_t> inv((size_t)n * Fr::N), partial((size_t)lanes * Fr::N);
+    std::vector<uint32_t> inv((size_t)n * Fr::N), partial((size_t)lanes * Fr::N), tsum((size_t)FR_QUOTIENT_SUM_LANES * Fr::N);
     FrQuotientArgs<Fr> a;
     a.poly = (const uint32_t*)poly;
     a.dom = (const uint32_t*)dom;
@@ -329,9 +335,12 @@ struct EmuCurve {
     a.K = K;
     a.inv = inv.data();
     a.partial = partial.data();
+    a.tsum = tsum.data();
     a.q = (uint32_t*)q;
     a.y = (uint32_t*)y;
     for (uint32_t l = 0; l < lanes; l++) fr_quotient_inv_body<Fr>(a, l);
+    for (uint32_t t = 0; t < FR_QUOTIENT_SUM_LANES; t++) fr_quotient_sum_body<Fr>(a, t, FR_QUOTIENT_SUM_LANES);
+    fr_quotient_y_body<Fr>(a, FR_QUOTIENT_SUM_LANES);
     for (uint32_t i = 0; i < n; i++) fr_quotient_out_body<Fr>(a, i);
   }
   static const EmuOps* ops() {

@@ -361,6 +361,64 @@ def test_horner_groups_and_merge_without_host_wait(dev, torch_cuda):
             dev.set_option(k, 0)
 
 
+def test_lone_msms_replay_their_graph(torch_cuda):
+    """Round 4: a caller that keeps nothing in flight gets the second call with the same inputs and plan captured into a HIP graph
+    and later ones replayed (MsmEngine::submit).  Same buffers with new contents, a workspace reallocation in between (the cached
+    graph holds workspace pointers by value), a changed plan, pipelined use in between, stage timings (no graph), cached bases."""
+    torch = torch_cuda
+    from constantine_amd import CachedBases, DeviceMsm
+    name = "bls12_381_g1"
+    eng = DeviceMsm(0)     # a fresh context: its workspace grows inside this test
+    try:
+        n = 20000
+        pts = cref.gen_points(name, 901, n)
+        sc1, sc2 = cref.synth_scalars(902, n, 255), cref.synth_scalars(903, n, 255)
+        exp1, exp2 = bytes(cref.msm(name, sc1, pts, nthreads=NT)[0]), bytes(cref.msm(name, sc2, pts, nthreads=NT)[0])
+        d_p, d_s = _to_dev(torch, pts), _to_dev(torch, sc1)
+        for _ in range(5):                                            # ordinary, captured, replayed ...
+            assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp1
+        d_s.copy_(torch.from_numpy(sc2))                              # same buffer, new contents
+        assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2
+        n2 = 300000                                                   # a larger MSM reallocates the workspace
+        pts2, sc3 = cref.gen_points(name, 904, n2), cref.synth_scalars(905, n2, 255)
+        exp3 = bytes(cref.msm(name, sc3, pts2, nthreads=NT)[0])
+        d_p2, d_s3 = _to_dev(torch, pts2), _to_dev(torch, sc3)
+        assert bytes(eng.msm(name, d_s3, d_p2, n2, coord="aff")) == exp3
+        for _ in range(4):
+            assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2
+            assert bytes(eng.msm(name, d_s3, d_p2, n2, coord="aff")) == exp3
+        eng.set_option("c", 11)                                       # another plan for the same inputs
+        for _ in range(3):
+            assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2
+        eng.set_option("c", 0)
+        a, b = eng.submit(name, d_s, d_p, n), eng.submit(name, d_s3, d_p2, n2)   # two in flight: no graphs, tail stream
+        assert bytes(eng.finish(a)) == exp2 and bytes(eng.finish(b)) == exp3
+        for _ in range(3):
+            assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2
+        eng.enable_timings(True)
+        assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2 and eng.last_timings()["total"] > 0
+        eng.enable_timings(False)
+        assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2
+        # prefixes of cached bases, host scalars staged through the context's buffer (the KZG commitment's call shape)
+        bases = CachedBases(name, pts, ctx=eng.ctx)
+        try:
+            for m, sc in ((n, sc1), (n, sc2), (n // 2, sc1[:n // 2]), (n, sc1), (n // 2, sc2[:n // 2]), (n, sc2), (n // 2, sc1[:n // 2])):
+                want = bytes(cref.msm(name, sc, pts[:m], nthreads=NT)[0])
+                assert bytes(bases.msm(sc, coord="aff")) == want, m
+        finally:
+            bases.close()
+        # another curve on the same context
+        pv = cref.gen_points("vesta", 906, 3000)
+        sv = cref.synth_scalars(907, 3000, 255)
+        ev = bytes(cref.msm("vesta", sv, pv, nthreads=NT)[0])
+        d_pv, d_sv = _to_dev(torch, pv), _to_dev(torch, sv)
+        for _ in range(4):
+            assert bytes(eng.msm("vesta", d_sv, d_pv, 3000, coord="aff")) == ev
+            assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2
+    finally:
+        eng.close()
+
+
 def test_tickets_finished_out_of_order(dev, torch_cuda):
     """with one ticket outstanding, blocking calls must keep working (whichever slot is free is taken)."""
     torch = torch_cuda
