@@ -511,41 +511,8 @@ struct HipBackend {
   }
   void d2h_async(int slot, void* dst_pinned, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst_pinned, src, b, hipMemcpyDeviceToHost, cur()));
-    if (!capturing) HIP_CHECK(hipEventRecord(ev_done[slot], cur()));   // (a captured MSM records it behind the graph launch)
+    HIP_CHECK(hipEventRecord(ev_done[slot], cur()));
   }
-  // ---- HIP graph of one lone MSM (MsmEngine::submit): the ~35 launches of a small MSM captured once per (inputs, plan) and
-  // replayed with one hipGraphLaunch.  Only for a caller that does not keep MSMs in flight (no tail stream inside a capture).
-  bool capturing = false;
-  bool graph_supported() const {
-    static const bool on = !(getenv("CTT_HIP_MSM_GRAPH") && atoi(getenv("CTT_HIP_MSM_GRAPH")) == 0);
-    return on && !timing;
-  }
-  void graph_begin() {
-    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    capturing = true;
-  }
-  // -> the instantiated graph (nullptr when the capture failed: the caller runs the MSM the ordinary way)
-  void* graph_end() {
-    hipGraph_t g = nullptr;
-    capturing = false;
-    if (hipStreamEndCapture(stream, &g) != hipSuccess || !g) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    hipGraphExec_t ex = nullptr;
-    const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    HIP_CHECK(hipGraphDestroy(g));
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    return (void*)ex;
-  }
-  void graph_launch(void* ex, int slot) {
-    HIP_CHECK(hipGraphLaunch((hipGraphExec_t)ex, stream));
-    HIP_CHECK(hipEventRecord(ev_done[slot], stream));
-  }
-  void graph_destroy(void* ex) { HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)ex)); }
   void d2h_wait(int slot) { HIP_CHECK(hipEventSynchronize(ev_done[slot])); }
   void d2h_sync(void* dst, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, stream));
@@ -720,6 +687,9 @@ struct CurveOps {
   int (*fr_quotient)(HipBackend* bk, const void* d_poly, const void* d_dom, const void* z_host, uint32_t n, void* d_work,
                      void* d_q, void* y_host);
   size_t fr_bytes;
+  // the same check on the host, for a handful of host-resident points (a precompile call, one commitment): a single GPU lane
+  // walks the 255 dependent doublings of [r]P in ~6.5 ms whatever n is, a CPU core needs ~0.2 ms per G1 point
+  void (*subgroup_check_host)(const void* pts_aff, size_t first, size_t step, size_t n, uint8_t* ok);
 };
 
 template <class C>
@@ -832,6 +802,20 @@ struct CurveImpl {
                        (const Affine<F>*)d_points, n, (uint8_t*)d_ok);
     HIP_CHECK(hipGetLastError());
   }
+  // points first, first + step, ... < n (one host thread's share)
+  static void subgroup_check_host(const void* pts_aff, size_t first, size_t step, size_t n, uint8_t* ok) {
+    using HF = typename Engine::HF;
+    using Fr = typename C::Fr;
+    const Affine<HF>* p = (const Affine<HF>*)pts_aff;
+    for (size_t j = first; j < n; j += step) {
+      XYZZ<HF> r = XYZZ<HF>::inf();
+      for (int i = 32 * Fr::N - 1; i >= 0; i--) {
+        r = xyzz_dbl<HF>(r);
+        if ((Fr::Params::P[i >> 5] >> (i & 31)) & 1u) xyzz_madd<HF>(r, p[j], false);
+      }
+      ok[j] = r.is_inf() ? 1 : 0;
+    }
+  }
   static int fr_quotient(HipBackend* bk, const void* d_poly, const void* d_dom, const void* z_host, uint32_t n, void* d_work,
                          void* d_q, void* y_host) {
     using Fr = typename C::Fr;
@@ -873,7 +857,7 @@ struct CurveImpl {
     return 0;
   }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F), subgroup_check, table_prepare, fr_quotient, sizeof(typename C::Fr)};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F), subgroup_check, table_prepare, fr_quotient, sizeof(typename C::Fr), subgroup_check_host};
     return &o;
   }
 };

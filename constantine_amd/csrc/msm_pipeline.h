@@ -354,13 +354,9 @@ struct MsmEngine {
     Buf* all[] = {&part, &gbase, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount, &cpoints, &totals};
     for (Buf* b : all) if (b->p) bk.free(b->p);
     for (Slot& sl : slots) if (sl.hraw) bk.free_host(sl.hraw);
-    for (GraphEntry& g : graphs) if (g.exec) bk.graph_destroy(g.exec);
   }
-  // Cached HIP graphs of lone MSMs hold the workspace pointers by value: any reallocation retires them (graph_gen).
-  uint32_t graph_gen = 0;
   void* need(Buf& b, size_t bytes) {
     if (bytes > b.cap) {
-      graph_gen++;
       if (b.p) bk.free(b.p);
       b.p = nullptr;
       b.cap = 0;
@@ -629,7 +625,6 @@ struct MsmEngine {
       if (S.hraw) bk.free_host(S.hraw);
       S.hraw = bk.alloc_host(bytes);
       S.hcap = bytes;
-      graph_gen++;
     }
     bk.d2h_async(sl, S.hraw, d_wsum, bytes);
     bk.stage_end(sl, ST_TOTAL);
@@ -659,46 +654,6 @@ struct MsmEngine {
     S.busy = true;
     S.empty = (n == 0);  // len == 0 is UB upstream; we return the neutral
     return sl;
-  }
-
-  // ---- HIP graphs for lone MSMs (round 4) ------------------------------------------------------------------------------
-  // A caller that does NOT keep MSMs in flight pays the host side of ~35 dependent launches per call (0.10-0.12 ms per submit,
-  // profiles/sweep_sizes_r03.jsonl) in front of the host tail.  The second call with the same inputs and plan is captured
-  // into a graph (the first sizes the workspace: no allocation may happen inside a capture), later ones replay it with one
-  // launch.  The key holds everything the captured kernel arguments were made from; a workspace reallocation retires every
-  // entry (graph_gen).  Pipelining callers are left alone: their tail runs on a second stream across two MSMs.
-  struct GraphEntry {
-    const void* coefs = nullptr;
-    const void* points = nullptr;
-    const void* prepared = nullptr;
-    uint32_t n = 0, table_n = 0, gen = 0;
-    int coef_is_fr = 0, table_c = 0, slot = 0;
-    MsmPlan plan;
-    void* exec = nullptr;   // nullptr: seen once, not captured yet
-    uint64_t used = 0;
-  };
-  std::vector<GraphEntry> graphs;
-  uint64_t graph_clock = 0;
-  static bool same_plan(const MsmPlan& a, const MsmPlan& b) {
-    return a.n == b.n && a.c == b.c && a.W == b.W && a.B == b.B && a.S == b.S && a.slice == b.slice && a.NG == b.NG && a.gshift == b.gshift &&
-           a.gshift_narrow == b.gshift_narrow && a.jbits == b.jbits && a.cap == b.cap && a.big == b.big && a.K == b.K && a.G == b.G &&
-           a.Wd == b.Wd && a.merged == b.merged && a.nent == b.nent && a.id_stride == b.id_stride && a.h == b.h && a.ngrp == b.ngrp &&
-           a.merge_steps == b.merge_steps;
-  }
-  GraphEntry* graph_lookup(const GraphEntry& k) {
-    for (size_t i = 0; i < graphs.size();) {
-      if (graphs[i].gen != graph_gen) {   // made before a reallocation: its pointers are stale
-        if (graphs[i].exec) bk.graph_destroy(graphs[i].exec);
-        graphs.erase(graphs.begin() + (long)i);
-      } else {
-        i++;
-      }
-    }
-    for (GraphEntry& g : graphs)
-      if (g.coefs == k.coefs && g.points == k.points && g.prepared == k.prepared && g.n == k.n && g.table_n == k.table_n &&
-          g.coef_is_fr == k.coef_is_fr && g.table_c == k.table_c && g.slot == k.slot && same_plan(g.plan, k.plan))
-        return &g;
-    return nullptr;
   }
 
   // One MSM on device-resident inputs.  d_prepared (optional): records made by prepare_bases for the same points; skips
@@ -741,43 +696,7 @@ struct MsmEngine {
     const MsmPlan p = table_c > 0 ? make_table_plan(n, C::BITS, table_c, table_n, po) : make_plan(n, C::BITS, po);
     slots[sl].plan = p;
     last_plan = p;
-    // a lone MSM (nothing else in flight): replay / capture its graph
-    GraphEntry* ge = nullptr;
-    bool capture = false;
-    if (!slots[sl ^ 1].busy && bk.graph_supported()) {
-      GraphEntry k;
-      k.coefs = d_coefs; k.points = d_points_in; k.prepared = d_prepared; k.n = n; k.table_n = table_n;
-      k.coef_is_fr = coef_is_fr ? 1 : 0; k.table_c = table_c; k.slot = sl; k.plan = p;
-      ge = graph_lookup(k);
-      if (ge && ge->exec) {
-        bk.tail_wait();
-        bk.wide_wait();
-        ge->used = ++graph_clock;
-        bk.graph_launch(ge->exec, sl);
-        return sl;
-      }
-      if (ge) {
-        capture = true;    // second sighting: the workspace has this plan's sizes
-      } else {
-        if (graphs.size() >= 16) {   // drop the least recently used entry
-          size_t lru = 0;
-          for (size_t i = 1; i < graphs.size(); i++) if (graphs[i].used < graphs[lru].used) lru = i;
-          if (graphs[lru].exec) bk.graph_destroy(graphs[lru].exec);
-          graphs.erase(graphs.begin() + (long)lru);
-        }
-        k.gen = graph_gen;
-        k.used = ++graph_clock;
-        graphs.push_back(k);
-        ge = nullptr;      // (the vector may have moved; this call runs the ordinary way)
-      }
-    }
-    const uint32_t gen_before = graph_gen;
     try {
-      if (capture) {
-        bk.tail_wait();
-        bk.wide_wait();
-        bk.graph_begin();
-      }
       bk.stage_begin(sl, ST_TOTAL);
       void* d_converted = nullptr;
       if constexpr (kConvert) {
@@ -787,28 +706,7 @@ struct MsmEngine {
       const Staged st = accumulate_pairs(sl, p, d_coefs, coef_is_fr, d_points_in, d_prepared, d_converted, d_buckets);
       merge_buckets(sl, p, st);
       reduce_buckets(sl, p, d_buckets);
-      if (capture) {
-        void* ex = bk.graph_end();
-        // (an allocation inside the capture cannot happen for a plan seen before; if it did, the graph is not trusted)
-        if (!ex || graph_gen != gen_before) {
-          fprintf(stderr, "[ctt_msm] FATAL: capture of an MSM graph failed\n");
-          abort();
-        }
-        ge = nullptr;
-        for (GraphEntry& g : graphs)
-          if (g.gen == graph_gen && !g.exec && g.coefs == d_coefs && g.points == d_points_in && g.prepared == d_prepared && g.n == n &&
-              g.slot == sl && g.table_c == table_c && same_plan(g.plan, p)) ge = &g;
-        if (ge) {
-          ge->exec = ex;
-          ge->used = ++graph_clock;
-          bk.graph_launch(ex, sl);
-        } else {
-          fprintf(stderr, "[ctt_msm] FATAL: lost the entry of a captured MSM graph\n");
-          abort();
-        }
-      }
     } catch (const OutOfDeviceMemory&) {
-      if (capture) (void)bk.graph_end();
       return release_slot(sl);
     }
     return sl;

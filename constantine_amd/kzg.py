@@ -63,9 +63,9 @@ def _buf(b):
 class EthereumKZGContext:
     """ctt_eth_kzg_context: srs_lagrange_brp_g1 cached on the GPU (constantine/commitments_setups/ethereum_kzg_srs.nim)."""
 
-    def __init__(self, srs_lagrange_g1_compressed: bytes, device=0, table=False):
+    def __init__(self, srs_lagrange_g1_compressed: bytes, device=0, table=True):
         """`srs_lagrange_g1_compressed`: 4096 x 48 bytes, the G1 Lagrange points in ceremony (file) order
-        (ctt_hip_eth_kzg_context_from_srs).  table=True caches the SRS as a window table."""
+        (ctt_hip_eth_kzg_context_from_srs).  table=True (what ctt_eth_kzg_context_new does) caches the SRS as a window table."""
         self.L = _lib.lib()
         if len(srs_lagrange_g1_compressed) != FIELD_ELEMENTS_PER_BLOB * 48:
             raise KzgError(cttEthKzgStatus.cttEthKzg_InputsLengthsMismatch)

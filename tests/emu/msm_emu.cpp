@@ -26,12 +26,6 @@ struct EmuBackend {
   void free_host(void* p) { ::free(p); }
   void d2h_async(int, void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void d2h_wait(int) {}
-  // (HIP graphs of lone MSMs are a device matter: hip_backend.h)
-  bool graph_supported() const { return false; }
-  void graph_begin() {}
-  void* graph_end() { return nullptr; }
-  void graph_launch(void*, int) {}
-  void graph_destroy(void*) {}
   void tail_begin() {}
   void tail_end() {}
   void tail_wait() {}

@@ -361,10 +361,12 @@ def test_horner_groups_and_merge_without_host_wait(dev, torch_cuda):
             dev.set_option(k, 0)
 
 
-def test_lone_msms_replay_their_graph(torch_cuda):
-    """Round 4: a caller that keeps nothing in flight gets the second call with the same inputs and plan captured into a HIP graph
-    and later ones replayed (MsmEngine::submit).  Same buffers with new contents, a workspace reallocation in between (the cached
-    graph holds workspace pointers by value), a changed plan, pipelined use in between, stage timings (no graph), cached bases."""
+def test_repeated_lone_calls_on_one_context(torch_cuda):
+    """Blocking calls on a fresh context, the way a caller without a pipeline uses it: the same buffers again and again, the same
+    buffers with new contents, a larger MSM in between (the grow-only workspace is reallocated), another plan for the same inputs,
+    two MSMs in flight in between, stage timings on and off, prefixes of cached bases, another curve on the same context.
+    (Round 4 wrote it for the HIP-graph replay of lone MSMs -- measured no gain, profiles/graph_lone_msm_r04.txt, code removed --
+    and it stays as the test of exactly the state that replay would have had to get right.)"""
     torch = torch_cuda
     from constantine_amd import CachedBases, DeviceMsm
     name = "bls12_381_g1"
@@ -375,7 +377,7 @@ def test_lone_msms_replay_their_graph(torch_cuda):
         sc1, sc2 = cref.synth_scalars(902, n, 255), cref.synth_scalars(903, n, 255)
         exp1, exp2 = bytes(cref.msm(name, sc1, pts, nthreads=NT)[0]), bytes(cref.msm(name, sc2, pts, nthreads=NT)[0])
         d_p, d_s = _to_dev(torch, pts), _to_dev(torch, sc1)
-        for _ in range(5):                                            # ordinary, captured, replayed ...
+        for _ in range(5):
             assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp1
         d_s.copy_(torch.from_numpy(sc2))                              # same buffer, new contents
         assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2
@@ -391,7 +393,7 @@ def test_lone_msms_replay_their_graph(torch_cuda):
         for _ in range(3):
             assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2
         eng.set_option("c", 0)
-        a, b = eng.submit(name, d_s, d_p, n), eng.submit(name, d_s3, d_p2, n2)   # two in flight: no graphs, tail stream
+        a, b = eng.submit(name, d_s, d_p, n), eng.submit(name, d_s3, d_p2, n2)   # two in flight: tail stream
         assert bytes(eng.finish(a)) == exp2 and bytes(eng.finish(b)) == exp3
         for _ in range(3):
             assert bytes(eng.msm(name, d_s, d_p, n, coord="aff")) == exp2
