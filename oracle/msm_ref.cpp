@@ -27,9 +27,15 @@
 //                                                      dispatch ec_multi_scalar_mul.nim:478-490 (round 3: rounds 1-2 kept Jacobian buckets throughout,
 //                                                      which understated the CPU baseline)
 //
-// Deliberate simplification (documented in DESIGN.md): no endomorphism pre-split is applied
-// (ec_multi_scalar_mul.nim:398-432) and the field inversion is a^(p-2), not the reference's division steps.
-// Both only change the operation count, never the group element returned.
+//   endomorphism pre-split on G1 (round 4) .......... constantine/math/elliptic/ec_multi_scalar_mul.nim:398-453 (applyEndomorphism, withEndo),
+//                                                      dispatch :455-490 (serial: c <= 13) and ec_multi_scalar_mul_parallel.nim:519-553 (parallel:
+//                                                      c in {2..6, 9, 10}); decomposition constantine/math/endomorphisms/split_scalars.nim:37-123
+//                                                      (Babai rounding with the lattices of named/constants/*_endomorphisms.nim);
+//                                                      phi(x, y) = (beta x, y), named/zoo_endomorphisms.nim:79-92.  BLS12-381, BN254-Snarks, Pallas,
+//                                                      Vesta G1 (M = 2: N -> 2N points, mini-scalars of ceil(bits/2) + 1 bits).
+//
+// Deliberate simplifications (documented in DESIGN.md): the G2 pre-split (M = 4, Frobenius psi) is not restated, and the field
+// inversion is a^(p-2), not the reference's division steps.  Both only change the operation count, never the group element returned.
 //
 // Build: g++ -O3 -march=native -shared -fPIC -pthread oracle/msm_ref.cpp -o oracle/libmsm_ref.so
 
@@ -592,6 +598,77 @@ static Jac<F> scalar_mul(const Scalar& k, const Aff<F>& p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Endomorphism pre-split on G1 (a = 0 curves: phi(x, y) = (beta x, y) = [lambda](x, y))
+// ------------------------------------------------------------------------------------------
+// 256-bit two's-complement helpers (the mini-scalars are ~128 bits; everything wraps mod 2^256 like the reference's BigInt[frBits])
+struct U256 { u64 l[4]; };
+static inline U256 u256_from(const u64* w, int n) { U256 r{{0, 0, 0, 0}}; for (int i = 0; i < n && i < 4; i++) r.l[i] = w[i]; return r; }
+static inline U256 u256_add(const U256& a, const U256& b) { U256 r; add_n<4>(r.l, a.l, b.l); return r; }
+static inline U256 u256_sub(const U256& a, const U256& b) { U256 r; sub_n<4>(r.l, a.l, b.l); return r; }
+static inline U256 u256_neg(const U256& a) { U256 z{{0, 0, 0, 0}}; return u256_sub(z, a); }
+// a (na limbs) * b (nb limbs), limbs [lo, lo + 4) of the exact product
+static inline U256 mul_limbs(const u64* a, int na, const u64* b, int nb, int lo) {
+  u64 t[12];
+  memset(t, 0, sizeof t);
+  for (int i = 0; i < na; i++) {
+    u64 c = 0;
+    for (int j = 0; j < nb; j++) {
+      u128 x = (u128)a[i] * b[j] + t[i + j] + c;
+      t[i + j] = (u64)x;
+      c = (u64)(x >> 64);
+    }
+    t[i + nb] += c;
+  }
+  U256 r{{0, 0, 0, 0}};
+  for (int i = 0; i < 4 && lo + i < na + nb; i++) r.l[i] = t[lo + i];
+  return r;
+}
+struct EndoG1 {
+  bool enabled = false;
+  u64 babai[2][3];      // (BigInt, isNeg) of named/constants/<curve>_endomorphisms.nim: <= 130 bits
+  bool babai_neg[2];
+  u64 lat[2][2][2];     // lattice[basis][miniscalar]: <= 128 bits
+  bool lat_neg[2][2];
+};
+static void hex3(const char* h, u64* out, int n) { hex_to_limbs(h, out, n); }
+// decomposeEndo (split_scalars.nim:37-123): alphas[i] = high words of babai[i] * k (w = 4 words), k_0 = k -+ sum alpha_i b_i0,
+// k_1 = -+ sum alpha_i b_i1; a negative mini-scalar is negated and its point with it (:112-123)
+static void decompose_endo(const EndoG1& E, const Scalar& k, Scalar mini[2], bool neg[2]) {
+  U256 alpha[2];
+  for (int i = 0; i < 2; i++) alpha[i] = mul_limbs(E.babai[i], 3, k.l, 4, 4);   // (babai_i * k) >> 256
+  U256 kk[2] = {u256_from(k.l, 4), U256{{0, 0, 0, 0}}};
+  for (int j = 0; j < 2; j++)
+    for (int i = 0; i < 2; i++) {
+      if ((E.lat[i][j][0] | E.lat[i][j][1]) == 0) continue;
+      const U256 ab = mul_limbs(alpha[i].l, 4, E.lat[i][j], 2, 0);
+      if (E.lat_neg[i][j] != E.babai_neg[i]) kk[j] = u256_add(kk[j], ab); else kk[j] = u256_sub(kk[j], ab);
+    }
+  for (int j = 0; j < 2; j++) {
+    neg[j] = (kk[j].l[3] >> 63) != 0;
+    if (neg[j]) kk[j] = u256_neg(kk[j]);
+    memcpy(mini[j].l, kk[j].l, sizeof(mini[j].l));
+  }
+}
+// applyEndomorphism (ec_multi_scalar_mul.nim:398-432): (k_i, P_i) -> (k_i0, +-P_i), (k_i1, +-phi(P_i)), interleaved as there
+template <class F>
+static void apply_endomorphism(const EndoG1& E, const F& beta, const Scalar* coefs, const Aff<F>* pts, size_t n,
+                               std::vector<Scalar>& ec, std::vector<Aff<F>>& ep) {
+  ec.resize(2 * n);
+  ep.resize(2 * n);
+  for (size_t i = 0; i < n; i++) {
+    bool neg[2];
+    decompose_endo(E, coefs[i], &ec[2 * i], neg);
+    Aff<F> p0 = pts[i], p1 = pts[i];
+    p1.x = F::mul(p1.x, beta);        // the neutral (0,0) stays (0,0)
+    if (neg[0]) p0.y = F::neg(p0.y);
+    if (neg[1]) p1.y = F::neg(p1.y);
+    ep[2 * i] = p0;
+    ep[2 * i + 1] = p1;
+  }
+}
+template <class F> struct EndoFor { static const EndoG1* get(int) { return nullptr; } static F beta(int) { return F::zero(); } };
+
+// ------------------------------------------------------------------------------------------
 // Curve table
 // ------------------------------------------------------------------------------------------
 
@@ -631,20 +708,39 @@ static u64 splitmix64(u64 x) {
   return z ^ (z >> 31);
 }
 
+// EndomorphismThreshold (zoo_endomorphisms.nim:124) and the two dispatch tables: serial c <= 13 (ec_multi_scalar_mul.nim:455-490),
+// parallel c in {2..6, 9, 10} (ec_multi_scalar_mul_parallel.nim:519-553); c is the window size chosen for (N, bits) BEFORE the split
+static bool endo_applies(int c_best, int bits, int nthreads) {
+  static const bool off = getenv("ORACLE_NO_ENDO") != nullptr;
+  if (off || bits < 152) return false;
+  return nthreads > 1 ? ((c_best >= 2 && c_best <= 6) || c_best == 9 || c_best == 10) : c_best <= 13;
+}
+
 template <class F>
-static int do_msm(const void* scalars, const void* points, size_t n, int bits, int nthreads, int c_override, void* out) {
+static int do_msm(int curve, const void* scalars, const void* points, size_t n, int bits, int nthreads, int c_override, void* out) {
   const Scalar* k = (const Scalar*)scalars;
   const Aff<F>* p = (const Aff<F>*)points;
   Aff<F>* o = (Aff<F>*)out;
   if (n == 0) { *o = {F::zero(), F::zero()}; return 0; }
   int c = c_override;
+  bool endo = false;
   if (c <= 0) {
     c = best_bucket_bit_size(n, bits, true, true);
+    endo = EndoFor<F>::get(curve) != nullptr && endo_applies(c, bits, nthreads);
     // parallel dispatch uses c-1 for c >= 11 (ec_multi_scalar_mul_parallel.nim:545-551); serial caps at 16
     if (nthreads > 1 && c >= 11) c -= 1;
     if (c > 16) c = 16;
   }
-  Jac<F> r = nthreads > 1 ? msm_parallel<F>(k, p, n, bits, c, nthreads) : msm_serial<F>(k, p, n, bits, c);
+  Jac<F> r;
+  if (endo) {
+    std::vector<Scalar> ec;
+    std::vector<Aff<F>> ep;
+    apply_endomorphism<F>(*EndoFor<F>::get(curve), EndoFor<F>::beta(curve), k, p, n, ec, ep);
+    const int L = (bits + 1) / 2 + 1;   // computeEndoRecodedLength (split_scalars.nim:315-316)
+    r = nthreads > 1 ? msm_parallel<F>(ec.data(), ep.data(), 2 * n, L, c, nthreads) : msm_serial<F>(ec.data(), ep.data(), 2 * n, L, c);
+  } else {
+    r = nthreads > 1 ? msm_parallel<F>(k, p, n, bits, c, nthreads) : msm_serial<F>(k, p, n, bits, c);
+  }
   *o = r.to_aff();
   return c;
 }
@@ -706,6 +802,50 @@ template <class F> static Aff<F> aff_from_u64(u64 x, u64 y) { return {F::from_u6
 static BlsFp fp_hex(const char* h) { BlsFp r; hex_to_limbs(h, r.l, 6); return BlsFp::to_mont(r); }
 static BnFp bn_hex(const char* h) { BnFp r; hex_to_limbs(h, r.l, 4); return BnFp::to_mont(r); }
 
+// lattices, Babai coefficients and cube roots of unity of named/constants/{bls12_381,bn254_snarks,pallas,vesta}_endomorphisms.nim
+struct EndoTable {
+  EndoG1 e[6];
+  BlsFp beta_bls;
+  BnFp beta_bn;
+  PallasFp beta_pallas;
+  VestaFp beta_vesta;
+};
+static EndoG1 make_endo(const char* l00, bool n00, const char* l01, bool n01, const char* l10, bool n10, const char* l11, bool n11,
+                        const char* b0, bool bn0, const char* b1, bool bn1) {
+  EndoG1 e;
+  e.enabled = true;
+  hex3(l00, e.lat[0][0], 2); hex3(l01, e.lat[0][1], 2); hex3(l10, e.lat[1][0], 2); hex3(l11, e.lat[1][1], 2);
+  e.lat_neg[0][0] = n00; e.lat_neg[0][1] = n01; e.lat_neg[1][0] = n10; e.lat_neg[1][1] = n11;
+  hex3(b0, e.babai[0], 3); hex3(b1, e.babai[1], 3);
+  e.babai_neg[0] = bn0; e.babai_neg[1] = bn1;
+  return e;
+}
+static const EndoTable& endo_table() {
+  static const EndoTable t = []() {
+    EndoTable t;
+    t.e[C_BLS_G1] = make_endo("ac45a4010001a4020000000100000000", false, "1", false, "1", false, "ac45a4010001a40200000000ffffffff", true,
+                              "17c6becf1e01faadd63f6e522f6cfee2e", false, "2", false);
+    t.e[C_BN_G1] = make_endo("6f4d8248eeb859fc8211bbeb7d4f1128", false, "89d3256894d213e3", true, "89d3256894d213e3", true,
+                             "6f4d8248eeb859fd0be4e1541221250b", true, "24ccef014a773d2d25398fd0300ff6565", false, "2d91d232ec7e0b3d7", true);
+    t.e[C_PALLAS] = make_endo("49e69d1640a899538cb1279300000000", true, "49e69d1640f049157fcae1c700000001", false,
+                              "93cd3a2c8198e2690c7c095a00000001", false, "49e69d1640a899538cb1279300000000", false,
+                              "1279a745902a2654e32c49e4bffffffff", true, "1279a745903c12455ff2b871c00000003", false);
+    t.e[C_VESTA] = make_endo("49e69d1640a899538cb1279300000001", true, "49e69d1640f049157fcae1c700000000", false,
+                             "93cd3a2c8198e2690c7c095a00000001", false, "49e69d1640a899538cb1279300000001", false,
+                             "1279a745902a2654e32c49e4c00000003", true, "1279a745903c12455ff2b871bffffffff", false);
+    t.beta_bls = fp_hex("5f19672fdf76ce51ba69c6076a0f77eaddb3a93be6f89688de17d813620a00022e01fffffffefffe");
+    t.beta_bn = bn_hex("30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48");
+    { PallasFp r; hex_to_limbs("2d33357cb532458ed3552a23a8554e5005270d29d19fc7d27b7fd22f0201b547", r.l, 4); t.beta_pallas = PallasFp::to_mont(r); }
+    { VestaFp r; hex_to_limbs("397e65a7d7c1ad71aee24b27e308f0a61259527ec1d4752e619d1840af55f1b1", r.l, 4); t.beta_vesta = VestaFp::to_mont(r); }
+    return t;
+  }();
+  return t;
+}
+template <> struct EndoFor<BlsFp> { static const EndoG1* get(int c) { return c == C_BLS_G1 ? &endo_table().e[c] : nullptr; } static BlsFp beta(int) { return endo_table().beta_bls; } };
+template <> struct EndoFor<BnFp> { static const EndoG1* get(int c) { return c == C_BN_G1 ? &endo_table().e[c] : nullptr; } static BnFp beta(int) { return endo_table().beta_bn; } };
+template <> struct EndoFor<PallasFp> { static const EndoG1* get(int c) { return c == C_PALLAS ? &endo_table().e[c] : nullptr; } static PallasFp beta(int) { return endo_table().beta_pallas; } };
+template <> struct EndoFor<VestaFp> { static const EndoG1* get(int c) { return c == C_VESTA ? &endo_table().e[c] : nullptr; } static VestaFp beta(int) { return endo_table().beta_vesta; } };
+
 extern "C" {
 
 // returns the window size c used (>0), or <0 on bad curve id. out = affine point in the C-API layout
@@ -714,12 +854,12 @@ int oracle_msm(int curve, const void* scalars, const void* points, size_t n, int
   ensure_init();
   int bits = curve_bits(curve);
   switch (curve) {
-    case C_BLS_G1: return do_msm<BlsFp>(scalars, points, n, bits, nthreads, c_override, out);
-    case C_BLS_G2: return do_msm<Fp2<BlsFp>>(scalars, points, n, bits, nthreads, c_override, out);
-    case C_BN_G1: return do_msm<BnFp>(scalars, points, n, bits, nthreads, c_override, out);
-    case C_BN_G2: return do_msm<Fp2<BnFp>>(scalars, points, n, bits, nthreads, c_override, out);
-    case C_PALLAS: return do_msm<PallasFp>(scalars, points, n, bits, nthreads, c_override, out);
-    case C_VESTA: return do_msm<VestaFp>(scalars, points, n, bits, nthreads, c_override, out);
+    case C_BLS_G1: return do_msm<BlsFp>(curve, scalars, points, n, bits, nthreads, c_override, out);
+    case C_BLS_G2: return do_msm<Fp2<BlsFp>>(curve, scalars, points, n, bits, nthreads, c_override, out);
+    case C_BN_G1: return do_msm<BnFp>(curve, scalars, points, n, bits, nthreads, c_override, out);
+    case C_BN_G2: return do_msm<Fp2<BnFp>>(curve, scalars, points, n, bits, nthreads, c_override, out);
+    case C_PALLAS: return do_msm<PallasFp>(curve, scalars, points, n, bits, nthreads, c_override, out);
+    case C_VESTA: return do_msm<VestaFp>(curve, scalars, points, n, bits, nthreads, c_override, out);
   }
   return -1;
 }
