@@ -87,8 +87,9 @@ CTT_HD XYZZ<F> xyzz_madd_same_x(const F& qx, const F& qy, bool same_y) {
 static constexpr int XYZZ_XB = 9;  // stored X < 9p (xyzz_madd's X3 = RR - PPP - 2Q + 7p); the other formulas give < 8p
 // `empty` carries "acc is the neutral element" in a flag instead of acc.zz == 0 (the accumulate kernel's form: no
 // 14-limb zero test per addition and no zero-fill when a bucket is flushed); when it is set acc's limbs are unspecified.
-template <class F>
-CTT_HD void xyzz_madd_flag(XYZZ<F>& acc, bool& empty, const F& qx, const F& qy_in, bool neg) {
+// `neg`: bool, or SignMask (fpu.h) -- the sign as a lane mask word, negated in arithmetic instead of through v_cndmask_b32
+template <class F, class S = bool>
+CTT_HD void xyzz_madd_flag(XYZZ<F>& acc, bool& empty, const F& qx, const F& qy_in, S neg) {
   constexpr int M = F::MULB;                                  // a product is < M*p, M = 2
   constexpr bool L1 = LazyOps<F>::ONE, L2 = LazyOps<F>::BOTH;
   constexpr int XB = XYZZ_XB;

@@ -185,6 +185,35 @@ struct FpU {
   CTT_HD static FpU cneg_lazy(const FpU& a, bool c) {
     return select(c, sub_lazy<B>(zero(), a), a);
   }
+  // The same two conditional negations with the condition as a lane MASK WORD m (0 or 0xffffffff, e.g. the sign bit of a sorted
+  // entry spread by an arithmetic shift) instead of a bool: bias - a = (a ^ ~0) + (bias + 1) in two's complement, so
+  //     r_i = (a_i ^ m) + ((bias_i + 1) & m)
+  // is a_i or bias_i - a_i with no compare and no v_cndmask_b32 -- which hipcc makes of every bool select, bfi idiom or not, and
+  // which costs 22 cycles per wave on gfx950 against 2.6 for the xor / and / add (profiles/microbench_isa_r02.jsonl; round 4:
+  // 14 of them sat in every iteration of the accumulate loop, 14 more in its bucket-start block).
+  template <int B>
+  CTT_HD static FpU cneg_lazy_m(const FpU& a, uint32_t m) {
+    constexpr KP c = kp(B + 1);
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const uint32_t bias = (i == 0) ? c.l[0] + (1u << LB) : (i == NL - 1) ? c.l[i] - 1u : c.l[i] + (1u << LB) - 1u;
+      r.l[i] = (a.l[i] ^ m) + ((bias + 1u) & m);
+    }
+    return r;
+  }
+  template <int B>
+  CTT_HD static FpU cneg_m(const FpU& a, uint32_t m) {
+    constexpr KP c = kp(B);
+    FpU r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const uint32_t bias = (i == 0) ? c.l[0] + (1u << LB) : (i == NL - 1) ? c.l[i] - 1u : c.l[i] + (1u << LB) - 1u;
+      r.l[i] = (a.l[i] ^ m) + ((bias + 1u) & m);
+    }
+    r.normalise();   // (a no-op on the lanes that keep a: its limbs are normalised already)
+    return r;
+  }
   CTT_HD static FpU norm(const FpU& a) {
     FpU r = a;
     r.normalise();
@@ -658,6 +687,20 @@ template <class F, int B, bool LZ> CTT_HD F fsub_lz(const F& a, const F& b) {
 }
 template <class F, int B, bool LZ> CTT_HD F fcneg_lz(const F& a, bool c) {
   if constexpr (LZ) return F::template cneg_lazy<B>(a, c); else return fcneg<F, B>(a, c);
+}
+// the condition as a lane mask word (0 / 0xffffffff): the carry-free base fields negate in arithmetic (FpU::cneg_m), every other
+// field takes it as the bool it stands for
+struct SignMask {
+  uint32_t m;
+  CTT_HD explicit SignMask(uint32_t entry_word) : m((uint32_t)((int32_t)entry_word >> 31)) {}   // sign = bit 31 of a sorted entry
+};
+template <class F> struct HasMaskNeg { static constexpr bool value = false; };
+template <class UP> struct HasMaskNeg<FpU<UP>> { static constexpr bool value = true; };
+template <class F, int B> CTT_HD F fcneg(const F& a, SignMask s) {
+  if constexpr (HasMaskNeg<F>::value) return F::template cneg_m<B>(a, s.m); else return fcneg<F, B>(a, s.m != 0u);
+}
+template <class F, int B, bool LZ> CTT_HD F fcneg_lz(const F& a, SignMask s) {
+  if constexpr (HasMaskNeg<F>::value && LZ) return F::template cneg_lazy_m<B>(a, s.m); else return fcneg<F, B>(a, s);
 }
 template <class F, bool LZ> CTT_HD F fnorm(const F& a) {
   if constexpr (LZ) return F::norm(a); else return a;

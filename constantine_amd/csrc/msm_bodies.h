@@ -159,6 +159,8 @@ struct SortArgs {
   uint32_t* entries;        // [W][nent]
   uint32_t* maxcount;       // [2]: largest bucket; scratch word
   uint32_t cap, big;        // k_group_sort: entries per LDS tile; buckets above `big` bypass the LDS image
+  uint32_t xcd_map = 1;     // partition kernels: neighbouring slices on one XCD (msm_engine.hip part_slice_of_block); 0 = slice b to block b
+  uint32_t staged = 1;      // pass A sweep 2 through an LDS image of the block's output (k_part_scatter_staged); 0 = one store per record
 };
 
 // Fr Montgomery -> canonical (batchFromField, finite_fields.nim:915-920)
@@ -313,7 +315,7 @@ CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq
     }
     gq.request(record(e1));                                        // entry pos+1 (the last one again at the end)
     const uint32_t e2 = ent[pos + 2 < p1 ? pos + 2 : plast];
-    if (!qinf) xyzz_madd_flag<F>(acc, empty, pt.x, pt.y, (e >> 31) != 0);
+    if (!qinf) xyzz_madd_flag<F, SignMask>(acc, empty, pt.x, pt.y, SignMask(e));
     e = e1;
     e1 = e2;
   }

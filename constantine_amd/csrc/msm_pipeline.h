@@ -51,6 +51,9 @@ struct MsmOptions {
   // cost model of the window choice: ns per mixed addition (accumulate) / per full addition (reduction) with the chip busy;
   // the engine fills in its curve's figures (msm_bodies.h curve descriptors), the defaults are BLS12-381 G1's
   double acc_ns = 0.142, red_ns = 0.26;
+  // sort pass A (msm_engine.hip): neighbouring slices on one XCD; records staged through LDS.  1 = on (default), 0 = the older form
+  // (kept for the groups beyond 1024 per window and for A/B runs: options "sort_xcd" / "sort_staged", $CTT_SORT_XCD / $CTT_SORT_STAGED)
+  int sort_xcd = 1, sort_staged = 1;
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -511,6 +514,8 @@ struct MsmEngine {
     sa.NG = p.NG; sa.gshift = p.gshift; sa.gshift_narrow = p.gshift_narrow; sa.slice = p.slice; sa.nblk = p.S;
     sa.jbits = p.jbits;
     sa.cap = p.cap; sa.big = p.big;
+    sa.xcd_map = opt.sort_xcd ? 1u : 0u;
+    sa.staged = opt.sort_staged ? 1u : 0u;
     sa.part = (uint32_t*)need(part, (size_t)W * p.nent * (p.merged ? 8 : 4));
     sa.cntA = (uint32_t*)need(counts, (size_t)p.S * W * p.NG * 4);
     sa.gtot = (uint32_t*)need(totals, (size_t)W * p.NG * 4);

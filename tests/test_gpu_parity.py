@@ -478,8 +478,20 @@ def test_sort_under_skewed_digit_distributions(dev, torch_cuda):
             for c in ((0, 11, 12, 13, 14, 15) if label == "uniform" else (0, 12)):   # 11..14: short top windows
                 dev.set_option("c", c)
                 assert bytes(dev.msm(name, _to_dev(torch, sc), dp, n, coord="aff")) == expect, (label, c)
+            # round 4: the partition pass has two forms (records staged through LDS / one store per record) and two block-to-slice
+            # mappings (XCD-aware / plain); the older forms still serve more than 1024 groups per window: every combination here
+            for staged, xcd in ((0, 0), (0, 1), (1, 0)):
+                dev.set_option("sort_staged", staged)
+                dev.set_option("sort_xcd", xcd)
+                for c in (0, 13):
+                    dev.set_option("c", c)
+                    assert bytes(dev.msm(name, _to_dev(torch, sc), dp, n, coord="aff")) == expect, (label, c, staged, xcd)
+            dev.set_option("sort_staged", 1)
+            dev.set_option("sort_xcd", 1)
     finally:
         dev.set_option("c", 0)
+        dev.set_option("sort_staged", 1)
+        dev.set_option("sort_xcd", 1)
 
 
 # ----------------------------------------------------------------------------------------------
