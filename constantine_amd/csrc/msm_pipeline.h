@@ -51,8 +51,12 @@ struct MsmOptions {
   // cost model of the window choice: ns per mixed addition (accumulate) / per full addition (reduction) with the chip busy;
   // the engine fills in its curve's figures (msm_bodies.h curve descriptors), the defaults are BLS12-381 G1's
   double acc_ns = 0.142, red_ns = 0.26;
-  // sort pass A (msm_engine.hip): neighbouring slices on one XCD; records staged through LDS.  1 = on (default), 0 = the older form
-  // (kept for the groups beyond 1024 per window and for A/B runs: options "sort_xcd" / "sort_staged", $CTT_SORT_XCD / $CTT_SORT_STAGED)
+  // sort pass A (msm_engine.hip).  sort_xcd: neighbouring slices on one XCD (1, default) or slice b to block b (0).  sort_staged:
+  // records staged through an LDS image of the block's output -- 1 = where it pays (default: from 256 bucket groups per window,
+  // i.e. ~2^22 pairs, on; measured, profiles/sort_staged_xcd_r04.txt: the sort of 2^22 / 2^24 BLS12-381 pairs 0.545 -> 0.486 /
+  // 2.26 -> 2.06 ms, BN254 2^22 0.526 -> 0.464, but 0.148 -> 0.173 ms at 2^20 and 0.056 -> 0.081 at 2^16: there a block has one or
+  // two window steps and the five barriers per step are what it sees), 2 = always, 0 = never (one store per record: the form
+  // that also serves more than 1024 groups).  Options "sort_xcd" / "sort_staged", $CTT_SORT_XCD / $CTT_SORT_STAGED.
   int sort_xcd = 1, sort_staged = 1;
 };
 
@@ -515,7 +519,7 @@ struct MsmEngine {
     sa.jbits = p.jbits;
     sa.cap = p.cap; sa.big = p.big;
     sa.xcd_map = opt.sort_xcd ? 1u : 0u;
-    sa.staged = opt.sort_staged ? 1u : 0u;
+    sa.staged = (opt.sort_staged >= 2 || (opt.sort_staged == 1 && p.NG >= 256u)) ? 1u : 0u;
     sa.part = (uint32_t*)need(part, (size_t)W * p.nent * (p.merged ? 8 : 4));
     sa.cntA = (uint32_t*)need(counts, (size_t)p.S * W * p.NG * 4);
     sa.gtot = (uint32_t*)need(totals, (size_t)W * p.NG * 4);

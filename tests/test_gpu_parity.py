@@ -480,7 +480,7 @@ def test_sort_under_skewed_digit_distributions(dev, torch_cuda):
                 assert bytes(dev.msm(name, _to_dev(torch, sc), dp, n, coord="aff")) == expect, (label, c)
             # round 4: the partition pass has two forms (records staged through LDS / one store per record) and two block-to-slice
             # mappings (XCD-aware / plain); the older forms still serve more than 1024 groups per window: every combination here
-            for staged, xcd in ((0, 0), (0, 1), (1, 0)):
+            for staged, xcd in ((0, 0), (0, 1), (2, 0), (2, 1)):
                 dev.set_option("sort_staged", staged)
                 dev.set_option("sort_xcd", xcd)
                 for c in (0, 13):
