@@ -742,7 +742,8 @@ struct MsmEngine {
     // An explicit request is honoured.
     // Round 3 (no host wait between the slices any more, profiles/hostptr_r03.txt): 2^18 1.93 (2 slices) / 2.03 (3), 2^20 6.08 (1) /
     // 5.00 (2) / 4.49 (3) / 4.58 (4), 2^22 22.3 / 17.2 / 15.5 / 14.4.
-    uint32_t cch = want > 0 ? (uint32_t)want : (n >= (1u << 21) ? 4u : n >= (3u << 18) ? 3u : n >= (3u << 17) ? 2u : 1u);
+    // Round 4 (profiles/hostptr_r04.txt, gpurun_out/r4a): 2^18 2.01 (1) / 1.89 (2) / 1.95 (3): two slices from 2^18 on (round 3: from 3 * 2^17).
+    uint32_t cch = want > 0 ? (uint32_t)want : (n >= (1u << 21) ? 4u : n >= (3u << 18) ? 3u : n >= (1u << 18) ? 2u : 1u);
     if (cch > 8) cch = 8;
     if (cch > n) cch = n;
     return cch < 1 ? 1 : cch;
