@@ -382,7 +382,7 @@ def main():
                 "frac_vs_round1_peak_31T": mads / t_acc / INT_MAD_PEAK_R01,
                 "note": "the multiply-adds are ~78 % of the kernel's VALU instructions; every VOP3 instruction issues at the same "
                         "~4.5 cycles per wave (profiles/microbench_isa_r02.jsonl), so the kernel's own roof is its instruction "
-                        "count: profiles/pmc_r03_sq_counters_k_accum_*.txt: 4539 VALU instructions per mixed addition for 3542 multiply-adds",
+                        "count: profiles/pmc_r04_sq_counters_k_accum_*.txt: 4558 VALU instructions per mixed addition for 3542 multiply-adds (DESIGN.md 4.3 has the account per class)",
             }
 
     # ---- the reference bench's own definition: one blocking call per iteration ----------------------------
