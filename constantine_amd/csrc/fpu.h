@@ -248,120 +248,56 @@ struct FpU {
 #if defined(__HIP_DEVICE_COMPILE__) && CTT_FPU_CHAIN
 #define CTT_FPU_ASM 1
 #define CTT_MADU(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\t"
-  // 1..14 dependent multiply-adds into acc per statement (hipcc pads every asm statement with one s_nop)
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0) {
-    asm(CTT_MADU(1, 2)
-        : "+v"(acc) : "v"(a0), "v"(b0) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9), "v"(a10), "v"(b10) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9), "v"(a10), "v"(b10), "v"(a11), "v"(b11) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11, uint32_t a12, uint32_t b12) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24) CTT_MADU(25, 26)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9), "v"(a10), "v"(b10), "v"(a11), "v"(b11), "v"(a12), "v"(b12) : "vcc");
-  }
-  CTT_HD static void madv(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11, uint32_t a12, uint32_t b12, uint32_t a13, uint32_t b13) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24) CTT_MADU(25, 26) CTT_MADU(27, 28)
-        : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9), "v"(a10), "v"(b10), "v"(a11), "v"(b11), "v"(a12), "v"(b12), "v"(a13), "v"(b13) : "vcc");
-  }
-  // second factor = a constant of the field (an SGPR; gfx9 VOP3 reads one SGPR per instruction)
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0) {
-    asm(CTT_MADU(1, 2)
-        : "+v"(acc) : "v"(a0), "s"(b0) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9), "v"(a10), "s"(b10) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9), "v"(a10), "s"(b10), "v"(a11), "s"(b11) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11, uint32_t a12, uint32_t b12) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24) CTT_MADU(25, 26)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9), "v"(a10), "s"(b10), "v"(a11), "s"(b11), "v"(a12), "s"(b12) : "vcc");
-  }
-  CTT_HD static void mads(uint64_t& acc, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9, uint32_t a10, uint32_t b10, uint32_t a11, uint32_t b11, uint32_t a12, uint32_t b12, uint32_t a13, uint32_t b13) {
-    asm(CTT_MADU(1, 2) CTT_MADU(3, 4) CTT_MADU(5, 6) CTT_MADU(7, 8) CTT_MADU(9, 10) CTT_MADU(11, 12) CTT_MADU(13, 14) CTT_MADU(15, 16) CTT_MADU(17, 18) CTT_MADU(19, 20) CTT_MADU(21, 22) CTT_MADU(23, 24) CTT_MADU(25, 26) CTT_MADU(27, 28)
-        : "+v"(acc) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5), "v"(a6), "s"(b6), "v"(a7), "s"(b7), "v"(a8), "s"(b8), "v"(a9), "s"(b9), "v"(a10), "s"(b10), "v"(a11), "s"(b11), "v"(a12), "s"(b12), "v"(a13), "s"(b13) : "vcc");
-  }
+  // 1..14 dependent multiply-adds into acc per statement (hipcc pads every asm statement with one s_nop), generated: the asm text, the
+  // parameter list and the operand list of a chain of N grow by one multiply-add per line; madv takes both factors in VGPRs, mads the
+  // second factor -- a constant of the field -- in an SGPR (gfx9 VOP3 reads one SGPR per instruction)
+#define CTT_MAD_ASM_1 CTT_MADU(1, 2)
+#define CTT_MAD_ASM_2 CTT_MAD_ASM_1 CTT_MADU(3, 4)
+#define CTT_MAD_ASM_3 CTT_MAD_ASM_2 CTT_MADU(5, 6)
+#define CTT_MAD_ASM_4 CTT_MAD_ASM_3 CTT_MADU(7, 8)
+#define CTT_MAD_ASM_5 CTT_MAD_ASM_4 CTT_MADU(9, 10)
+#define CTT_MAD_ASM_6 CTT_MAD_ASM_5 CTT_MADU(11, 12)
+#define CTT_MAD_ASM_7 CTT_MAD_ASM_6 CTT_MADU(13, 14)
+#define CTT_MAD_ASM_8 CTT_MAD_ASM_7 CTT_MADU(15, 16)
+#define CTT_MAD_ASM_9 CTT_MAD_ASM_8 CTT_MADU(17, 18)
+#define CTT_MAD_ASM_10 CTT_MAD_ASM_9 CTT_MADU(19, 20)
+#define CTT_MAD_ASM_11 CTT_MAD_ASM_10 CTT_MADU(21, 22)
+#define CTT_MAD_ASM_12 CTT_MAD_ASM_11 CTT_MADU(23, 24)
+#define CTT_MAD_ASM_13 CTT_MAD_ASM_12 CTT_MADU(25, 26)
+#define CTT_MAD_ASM_14 CTT_MAD_ASM_13 CTT_MADU(27, 28)
+#define CTT_MAD_PAR_1 uint32_t a0, uint32_t b0
+#define CTT_MAD_PAR_2 CTT_MAD_PAR_1, uint32_t a1, uint32_t b1
+#define CTT_MAD_PAR_3 CTT_MAD_PAR_2, uint32_t a2, uint32_t b2
+#define CTT_MAD_PAR_4 CTT_MAD_PAR_3, uint32_t a3, uint32_t b3
+#define CTT_MAD_PAR_5 CTT_MAD_PAR_4, uint32_t a4, uint32_t b4
+#define CTT_MAD_PAR_6 CTT_MAD_PAR_5, uint32_t a5, uint32_t b5
+#define CTT_MAD_PAR_7 CTT_MAD_PAR_6, uint32_t a6, uint32_t b6
+#define CTT_MAD_PAR_8 CTT_MAD_PAR_7, uint32_t a7, uint32_t b7
+#define CTT_MAD_PAR_9 CTT_MAD_PAR_8, uint32_t a8, uint32_t b8
+#define CTT_MAD_PAR_10 CTT_MAD_PAR_9, uint32_t a9, uint32_t b9
+#define CTT_MAD_PAR_11 CTT_MAD_PAR_10, uint32_t a10, uint32_t b10
+#define CTT_MAD_PAR_12 CTT_MAD_PAR_11, uint32_t a11, uint32_t b11
+#define CTT_MAD_PAR_13 CTT_MAD_PAR_12, uint32_t a12, uint32_t b12
+#define CTT_MAD_PAR_14 CTT_MAD_PAR_13, uint32_t a13, uint32_t b13
+#define CTT_MAD_OPS_1(BC) "v"(a0), BC(b0)
+#define CTT_MAD_OPS_2(BC) CTT_MAD_OPS_1(BC), "v"(a1), BC(b1)
+#define CTT_MAD_OPS_3(BC) CTT_MAD_OPS_2(BC), "v"(a2), BC(b2)
+#define CTT_MAD_OPS_4(BC) CTT_MAD_OPS_3(BC), "v"(a3), BC(b3)
+#define CTT_MAD_OPS_5(BC) CTT_MAD_OPS_4(BC), "v"(a4), BC(b4)
+#define CTT_MAD_OPS_6(BC) CTT_MAD_OPS_5(BC), "v"(a5), BC(b5)
+#define CTT_MAD_OPS_7(BC) CTT_MAD_OPS_6(BC), "v"(a6), BC(b6)
+#define CTT_MAD_OPS_8(BC) CTT_MAD_OPS_7(BC), "v"(a7), BC(b7)
+#define CTT_MAD_OPS_9(BC) CTT_MAD_OPS_8(BC), "v"(a8), BC(b8)
+#define CTT_MAD_OPS_10(BC) CTT_MAD_OPS_9(BC), "v"(a9), BC(b9)
+#define CTT_MAD_OPS_11(BC) CTT_MAD_OPS_10(BC), "v"(a10), BC(b10)
+#define CTT_MAD_OPS_12(BC) CTT_MAD_OPS_11(BC), "v"(a11), BC(b11)
+#define CTT_MAD_OPS_13(BC) CTT_MAD_OPS_12(BC), "v"(a12), BC(b12)
+#define CTT_MAD_OPS_14(BC) CTT_MAD_OPS_13(BC), "v"(a13), BC(b13)
+#define CTT_MAD_DEF(N)                                                                                                              \
+  CTT_HD static void madv(uint64_t& acc, CTT_MAD_PAR_##N) { asm(CTT_MAD_ASM_##N : "+v"(acc) : CTT_MAD_OPS_##N("v") : "vcc"); }    \
+  CTT_HD static void mads(uint64_t& acc, CTT_MAD_PAR_##N) { asm(CTT_MAD_ASM_##N : "+v"(acc) : CTT_MAD_OPS_##N("s") : "vcc"); }
+  CTT_MAD_DEF(1) CTT_MAD_DEF(2) CTT_MAD_DEF(3) CTT_MAD_DEF(4) CTT_MAD_DEF(5) CTT_MAD_DEF(6) CTT_MAD_DEF(7)
+  CTT_MAD_DEF(8) CTT_MAD_DEF(9) CTT_MAD_DEF(10) CTT_MAD_DEF(11) CTT_MAD_DEF(12) CTT_MAD_DEF(13) CTT_MAD_DEF(14)
 #else
 #define CTT_FPU_ASM 0
 #endif
