@@ -802,11 +802,51 @@ struct CurveImpl {
                        (const Affine<F>*)d_points, n, (uint8_t*)d_ok);
     HIP_CHECK(hipGetLastError());
   }
+  // [|x|]P for the BLS12-381 parameter |x| = 0xd201000000010000 (pow_bls12_381_abs_x, named/constants/bls12_381_subgroups.nim:20-45):
+  // 63 doublings and 5 additions
+  template <class HF>
+  static XYZZ<HF> bls12_381_mul_abs_x(const Affine<HF>& P) {
+    XYZZ<HF> r = xyzz_mdbl<HF>(P.x, P.y);
+    xyzz_madd<HF>(r, P, false);                                   // 0b11
+    static const int runs[5] = {2, 3, 9, 32, 16};
+    for (int k = 0; k < 5; k++) {
+      for (int i = 0; i < runs[k]; i++) r = xyzz_dbl<HF>(r);
+      if (k < 4) xyzz_madd<HF>(r, P, false);                      // 0b1101, 0b1101001, ...0000001, ...00000001, then 16 doublings
+    }
+    return r;
+  }
   // points first, first + step, ... < n (one host thread's share)
   static void subgroup_check_host(const void* pts_aff, size_t first, size_t step, size_t n, uint8_t* ok) {
     using HF = typename Engine::HF;
     using Fr = typename C::Fr;
     const Affine<HF>* p = (const Affine<HF>*)pts_aff;
+    if constexpr (std::is_same<C, Bls12381G1>::value) {
+      // The reference's own test for this group (isInSubgroup, bls12_381_subgroups.nim:170-191; Scott, eprint 2021/1130): P is in G1 iff
+      // phi(P) = [-x^2]P with phi(X, Y) = (beta X, Y), beta = BLS12_381_cubicRootOfUnity_mod_p -- 126 doublings and 10 additions
+      // instead of 255 and ~128.  tests/test_batch_ops.py checks it against [r]P = neutral on points inside and outside the subgroup.
+      static const HF beta = []() {
+        // 0x5f19672fdf76ce51ba69c6076a0f77eaddb3a93be6f89688de17d813620a00022e01fffffffefffe (named/constants/bls12_381_endomorphisms.nim:18-19)
+        static const uint64_t w[6] = {0x2e01fffffffefffeull, 0xde17d813620a0002ull, 0xddb3a93be6f89688ull, 0xba69c6076a0f77eaull, 0x5f19672fdf76ce51ull, 0x0ull};
+        HF b, r2;
+        for (int i = 0; i < HF::N; i++) {
+          b.l[i] = w[i];
+          r2.l[i] = (uint64_t)HF::Params::R2[2 * i] | ((uint64_t)HF::Params::R2[2 * i + 1] << 32);
+        }
+        return HF::mul(b, r2);
+      }();
+      for (size_t j = first; j < n; j += step) {
+        const Affine<HF> P = p[j];
+        if (P.is_inf()) { ok[j] = 1; continue; }
+        const Affine<HF> t0 = xyzz_to_affine<HF>(bls12_381_mul_abs_x<HF>(P));          // [|x|]P
+        if (t0.is_inf()) { ok[j] = 0; continue; }
+        const XYZZ<HF> t1 = bls12_381_mul_abs_x<HF>(t0);                               // [x^2]P; the test is phi(P) == -t1
+        if (t1.is_inf()) { ok[j] = 0; continue; }
+        const bool same_x = HF::eq(t1.x, HF::mul(HF::mul(P.x, beta), t1.zz));
+        const bool opp_y = HF::add(t1.y, HF::mul(P.y, t1.zzz)).is_zero();
+        ok[j] = (same_x && opp_y) ? 1 : 0;
+      }
+      return;
+    }
     for (size_t j = first; j < n; j += step) {
       XYZZ<HF> r = XYZZ<HF>::inf();
       for (int i = 32 * Fr::N - 1; i >= 0; i--) {

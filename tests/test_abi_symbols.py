@@ -89,3 +89,39 @@ def test_host_mirror_argument_checks():
         msm.multiScalarMul_vartime_parallel(None, "bls12_381_g2", np.zeros((1, 32), np.uint8), np.zeros((1, 192), np.uint8))
     with pytest.raises(AssertionError):
         msm.CttEngine().msm(np.zeros((2, 32), np.uint8), np.zeros((1, 64), np.uint8))
+
+
+def test_subgroup_check_of_a_few_host_points_runs_on_the_host():
+    """ctt_hip_subgroup_check with <= 64 host-resident points never touches the GPU (one GPU lane needs 6.5 ms for [r]P): the generic
+    [r]P = neutral on the host for every curve, and for BLS12-381 G1 the reference's endomorphism test phi(P) = [-x^2]P
+    (bls12_381_subgroups.nim:170-191).  Against the big-integer oracle on subgroup points, curve points outside the subgroup, a point
+    of order 3 and the neutral."""
+    import random
+    from constantine_amd.msm import subgroup_check
+    from oracle import cref
+    from oracle import pyoracle as po
+    rng = random.Random(17)
+    for name in ("bls12_381_g1", "bn254_snarks_g1", "bls12_381_g2"):
+        curve = po.CURVES[name]
+        F = curve.F
+        inside = [curve.aff_from_bytes(bytes(b)) for b in cref.gen_points(name, 9, 6)]
+        outside = []
+        if name == "bls12_381_g1":
+            p = F.p
+            while len(outside) < 6:            # random points of the curve: the cofactor is ~2^126, so almost never in the subgroup
+                x = rng.randrange(p)
+                y2 = (x * x * x + 4) % p
+                y = pow(y2, (p + 1) // 4, p)
+                if y * y % p == y2:
+                    outside.append((x, y))
+            outside.append((0, 2))             # x = 0: a point of order 3
+        pts = inside + outside + [None]
+        want = [curve.scalar_mul(curve.order, P) is None for P in pts]
+        assert want[:6] == [True] * 6 and want[-1] is True
+        if outside:
+            assert not any(want[6:-1])
+        got = subgroup_check(name, curve.points_to_array(pts))
+        assert [bool(v) for v in got] == want, name
+        # the 16-thread split
+        many = curve.points_to_array((pts * 5)[:60])
+        assert [bool(v) for v in subgroup_check(name, many)] == (want * 5)[:60], name

@@ -18,6 +18,7 @@ from tests import _golden
 pytestmark = pytest.mark.gpu
 
 ALL = list(po.CURVES)
+CURVE_COORD_BYTES = {"bls12_381_g1": 48, "bls12_381_g2": 96, "bn254_snarks_g1": 32, "bn254_snarks_g2": 64, "pallas": 32, "vesta": 32}
 G1S = ["bls12_381_g1", "bn254_snarks_g1", "pallas", "vesta"]
 NT = max(1, min(32, os.cpu_count() or 1))  # the GPU box grants a 16-CPU quota
 
@@ -862,6 +863,38 @@ def test_window_table_full_size_vs_oracle(name, log2n):
             bases.close()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_neutral_host_pointer_symbols(name):
+    """Header part 1c (round 4): ctt_hip_msm_<curve>_<coord>_<coefs> and ctt_hip_msm_host give the Constantine symbols' result and a status
+    instead of an abort -- what a binding inside libconstantine imports (INTEGRATION.md part B)."""
+    from constantine_amd import msm_available, msm_host, multiScalarMul_vartime
+    from constantine_amd import _lib
+    import ctypes
+    assert msm_available()
+    curve = po.CURVES[name]
+    n = 777
+    pts = cref.gen_points(name, 3100, n)
+    sc = cref.synth_scalars(3101, n, curve.scalar_bits)
+    expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
+    for coord in ("jac", "prj"):
+        assert _decode(curve, coord, msm_host(name, sc, pts, coord=coord)) == expect
+        assert _decode(curve, coord, msm_host(name, sc, pts, coord=coord, typed=False)) == expect
+        assert bytes(msm_host(name, sc, pts, coord=coord)) == bytes(multiScalarMul_vartime(name, sc, pts, coord=coord))
+    assert _decode(curve, "aff", msm_host(name, sc, pts, coord="aff")) == expect
+    mont = cref.fr_to_mont(name, sc) if hasattr(cref, "fr_to_mont") else None
+    if mont is not None:
+        red = cref.fr_from_mont(name, mont)
+        exp_fr = _aff(curve, cref.msm(name, red, pts, nthreads=NT)[0])
+        assert _decode(curve, "jac", msm_host(name, mont, pts, coord="jac", fr_coefs=True)) == exp_fr
+    # refusals come back as a status, r untouched
+    L = _lib.lib()
+    r = np.full(3 * CURVE_COORD_BYTES[name], 0xAB, dtype=np.uint8)
+    for args in ((17, 0, 1), (0, 5, 1), (0, 0, 9)):
+        assert L.ctt_hip_msm_host(args[0], args[1], args[2], r.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p),
+                                  pts.ctypes.data_as(ctypes.c_void_p), n) == -1
+    assert (r == 0xAB).all()
 
 
 def test_c_program_through_the_header(tmp_path):
