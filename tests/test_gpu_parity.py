@@ -810,6 +810,8 @@ def test_window_table_cached_bases_vs_oracle(name):
     pts = cref.gen_points(name, 911, n)
     pts[11] = 0
     pts[13] = pts[12]
+    from constantine_amd import _lib
+    set_default = lambda k, v: _lib.lib().ctt_hip_msm_set_option(None, k.encode(), int(v))   # noqa: E731  (the default context's options)
     for wb in (0, 5, 12, 15) if curve.F.degree == 1 else (0, 9):
         bases = CachedBases(name, pts, table=True, window_bits=wb)
         try:
@@ -820,6 +822,13 @@ def test_window_table_cached_bases_vs_oracle(name):
                     sc[13] = sc[12]
                 expect = _aff(curve, cref.msm(name, sc, pts[:m], nthreads=NT)[0])
                 assert _decode(curve, "jac", bases.msm(sc, coord="jac")) == expect, (name, wb, m)
+                # both forms of the partition pass's second sweep on the merged (one bucket set, 64-bit records) sort (round 4)
+                try:
+                    for staged in (0, 2):
+                        set_default("sort_staged", staged)
+                        assert _decode(curve, "jac", bases.msm(sc, coord="jac")) == expect, (name, wb, m, staged)
+                finally:
+                    set_default("sort_staged", 1)
             if curve.F.degree == 1:
                 mont = cref.synth_scalars(5, n, 250)
                 expect = _aff(curve, cref.msm(name, cref.fr_from_mont(name, mont), pts, nthreads=NT)[0])
@@ -912,13 +921,18 @@ def test_c_program_through_the_header(tmp_path):
     n = 1500
     pts = cref.gen_points(name, 77, n)
     sc = cref.synth_scalars(78, n, 255)
+    import json
+    doc = json.load(open(os.path.join(_golden.HERE, "eip2537_multiexp.json")))
+    evm_name, evm_in, evm_exp = max(doc["g1"], key=lambda c: len(c[1]))          # the longest of the reference's G1MSM vectors
     with open(tmp_path / "in.bin", "wb") as f:
         f.write(np.uint64(n).tobytes())
         f.write(sc.tobytes())
         f.write(pts.tobytes())
+        f.write(np.uint64(len(evm_in) // 2).tobytes())
+        f.write(bytes.fromhex(evm_in))
     subprocess.check_call([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
     out = open(tmp_path / "out.bin", "rb").read()
-    assert len(out) == 6 * 144 + n
+    assert len(out) == 6 * 144 + n + 128
     expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
     assert curve.jac_from_bytes(out[:144]) == expect
     assert curve.prj_from_bytes(out[144:288]) == expect
@@ -926,7 +940,8 @@ def test_c_program_through_the_header(tmp_path):
     assert curve.jac_from_bytes(out[432:576]) == expect          # cached bases with a window table
     assert curve.jac_from_bytes(out[576:720]) == expect          # neutral typed symbol (what the Nim binding imports)
     assert curve.prj_from_bytes(out[720:864]) == expect          # neutral generic symbol
-    assert out[864:] == b"\x01" * n                                # every generated point is in the subgroup
+    assert out[864:864 + n] == b"\x01" * n                        # every generated point is in the subgroup
+    assert out[864 + n:] == bytes.fromhex(evm_exp), evm_name       # the precompile symbol called from C
 
 
 def test_concurrent_callers_are_serialised():
