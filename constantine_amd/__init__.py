@@ -9,7 +9,7 @@ Only what the MSM hot path needs lives here:
   parallel.py  point-sharded multi-GPU MSM, one process per GPU (torch.distributed / RCCL); the in-library form, one
             process driving several GPUs, is ctt_hip_msm_set_devices / $CTT_HIP_DEVICES (msm.set_devices)
   synth.py  synthetic benchmark inputs (seeded scalars)
-  kzg.py    the MSM's immediate caller: EIP-4844 blob -> KZG commitment and opening proofs over a cached SRS
+  kzg.py, evm.py  ctypes callers of the reference's KZG / EIP-2537 MSM-precompile C symbols (csrc/protocols.hip: host side in C++)
 """
 from .curves import CURVES, CurveInfo  # noqa: F401
 from .msm import (  # noqa: F401
