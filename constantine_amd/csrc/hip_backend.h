@@ -425,6 +425,7 @@ struct HipBackend {
     HIP_CHECK(hipStreamWaitEvent(aux, ev_tail_fork, 0));
     on_aux = true;
   }
+  bool tail_forked() const { return on_aux; }
   void tail_end() {
     if (no_tail) return;
     HIP_CHECK(hipEventRecord(ev_tail_done, aux));
@@ -540,7 +541,7 @@ struct HipBackend {
     }
     if (!stage_on(s)) return;
     const int ch = (s == ST_TOTAL || s == ST_REDUCE) ? 0 : chunk;
-    HIP_CHECK(hipEventRecord(ev_begin[slot][s][ch], stream));
+    HIP_CHECK(hipEventRecord(ev_begin[slot][s][ch], cur()));
     ev_used[slot][s] |= 1u << ch;
   }
   void stage_end(int slot, int s) {
@@ -599,25 +600,25 @@ struct HipBackend {
   }
   template <class F>
   void launch_merge_tail(const MergeArgs<F>& a, uint32_t W) {
-    hipLaunchKernelGGL(k_merge_tail<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(k_merge_tail<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
   void launch_merge_step(const MergeArgs<F>& a, uint32_t W, uint32_t d) {
     if ((uint64_t)a.G * W * 4u <= 1048576u) {  // the additions of a step are sparse: four lanes each
-      hipLaunchKernelGGL(k_merge_step_quad<F>, grid2(a.G * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, d);
+      hipLaunchKernelGGL(k_merge_step_quad<F>, grid2(a.G * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, d);
       HIP_CHECK(hipGetLastError());
       return;
     }
-    hipLaunchKernelGGL(k_merge_step<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a, d);
+    hipLaunchKernelGGL(k_merge_step<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, d);
     HIP_CHECK(hipGetLastError());
   }
   // the steps beyond those the plan enqueued (unusual inputs only: returns at once otherwise), then the chain heads -> buckets
   template <class F>
   void launch_merge_finish(const MergeArgs<F>& a, uint32_t W, uint32_t first_d) {
-    hipLaunchKernelGGL(k_merge_finish<F>, dim3(W), dim3(RED_BLOCK), 0, stream, a, first_d);
+    hipLaunchKernelGGL(k_merge_finish<F>, dim3(W), dim3(RED_BLOCK), 0, cur(), a, first_d);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_merge_final<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(k_merge_final<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>

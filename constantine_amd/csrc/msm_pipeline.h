@@ -58,6 +58,7 @@ struct MsmOptions {
   // two window steps and the five barriers per step are what it sees), 2 = always, 0 = never (one store per record: the form
   // that also serves more than 1024 groups).  Options "sort_xcd" / "sort_staged", $CTT_SORT_XCD / $CTT_SORT_STAGED.
   int sort_xcd = 1, sort_staged = 1;
+  int early_tail = 1;   // MsmEngine::submit: merge + every reduction pass on the tail stream for large pipelined MSMs (0 off, 1 automatic, 2 always)
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -354,11 +355,13 @@ struct MsmEngine {
 
   // grow-only workspace
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf part, counts, bstart, entries, buckets, heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcount, cpoints, totals, gbase;
+  // bstartS / maxcountS / bucketsS: one per in-flight slot -- the head merge and the first reduction pass of MSM i read them on the tail
+  // stream while the sort of MSM i+1 already writes its own (submit(): early tail)
+  Buf part, counts, bstartS[2], entries, bucketsS[2], heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcountS[2], cpoints, totals, gbase;
 
   explicit MsmEngine(BK& b) : bk(b) {}
   ~MsmEngine() {
-    Buf* all[] = {&part, &gbase, &counts, &bstart, &entries, &buckets, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcount, &cpoints, &totals};
+    Buf* all[] = {&part, &gbase, &counts, &bstartS[0], &bstartS[1], &entries, &bucketsS[0], &bucketsS[1], &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcountS[0], &maxcountS[1], &cpoints, &totals};
     for (Buf* b : all) if (b->p) bk.free(b->p);
     for (Slot& sl : slots) if (sl.hraw) bk.free_host(sl.hraw);
   }
@@ -468,16 +471,16 @@ struct MsmEngine {
   };
   // the grow-only workspace of stage 1 sized for plan p up front (need() frees and reallocates -- a device-wide
   // synchronisation -- when a later, larger slice of a host-pointer MSM asks for more)
-  void reserve_stage1(const MsmPlan& p, bool coef_is_fr) {
+  void reserve_stage1(int sl, const MsmPlan& p, bool coef_is_fr) {
     const size_t W = p.W, n = p.nent;
     if (coef_is_fr) need(scal, (size_t)p.n * 32);
     need(part, W * n * (p.merged ? 8 : 4));
     need(counts, (size_t)p.S * W * p.NG * 4);
     need(totals, W * p.NG * 4);
     need(gbase, W * (p.NG + 1) * 4);
-    need(bstart, W * (p.B + 1) * 4);
+    need(bstartS[sl], W * (p.B + 1) * 4);
     need(entries, W * n * 4);
-    need(maxcount, 256);
+    need(maxcountS[sl], 256);
     need(heads, W * p.G * sizeof(XYZZ<FD>));
     need(tails, W * p.G * sizeof(XYZZ<FD>));
     need(hkey, W * p.G * 4);
@@ -525,9 +528,9 @@ struct MsmEngine {
     sa.gtot = (uint32_t*)need(totals, (size_t)W * p.NG * 4);
     sa.gbase = (uint32_t*)need(gbase, (size_t)W * (p.NG + 1) * 4);
     Staged st;
-    st.d_bstart = (uint32_t*)need(bstart, (size_t)W * (B + 1) * 4);
+    st.d_bstart = (uint32_t*)need(bstartS[sl], (size_t)W * (B + 1) * 4);
     uint32_t* d_entries = (uint32_t*)need(entries, (size_t)W * p.nent * 4);
-    st.d_maxcount = (uint32_t*)need(maxcount, 256);
+    st.d_maxcount = (uint32_t*)need(maxcountS[sl], 256);
     bk.memset0(st.d_maxcount, 8);
     sa.bstart = st.d_bstart; sa.entries = d_entries; sa.maxcount = st.d_maxcount;
     bk.launch_digits_sort(sa);   // (leaves the largest bucket in d_maxcount[0]: the merge kernels read it there)
@@ -587,7 +590,8 @@ struct MsmEngine {
   void reduce_buckets(int sl, const MsmPlan& p, XYZZ<FD>* d_buckets) {
     Slot& S = slots[sl];
     const uint32_t W = p.W, B = p.B;
-    bk.tail_wait();   // (a no-op unless accumulate_pairs left the previous tail running: small MSMs)
+    const bool forked_early = bk.tail_forked();   // submit() forked in front of the head merge (early tail)
+    if (!forked_early) bk.tail_wait();   // (a no-op unless accumulate_pairs left the previous tail running: small MSMs)
     bk.stage_begin(sl, ST_REDUCE);
     XYZZ<FD>* d_pyr = (XYZZ<FD>*)need(rA[0], (size_t)W * B * sizeof(XYZZ<FD>));
     XYZZ<FD>* d_q = (XYZZ<FD>*)need(rA[1], (size_t)W * (B / 2 + 1) * sizeof(XYZZ<FD>));
@@ -606,7 +610,7 @@ struct MsmEngine {
     // 10.75; no difference for the other curves -- the kernels do slow each other down (round 2 measured the sort 0.19 -> 0.23 ms
     // under wide passes), a quarter of the overlap is what remains.
     static const bool wide_early = !(getenv("CTT_HIP_MSM_WIDE_EARLY") && atoi(getenv("CTT_HIP_MSM_WIDE_EARLY")) == 0);
-    bool forked = false, marked = false;
+    bool forked = forked_early, marked = false;
     for (int pass = 0; pass <= p.c - 2; pass++) {
       PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass, 1u};
       const uint32_t ntasks = pyr_pass_tasks(B, p.c, pass);
@@ -711,14 +715,31 @@ struct MsmEngine {
       if constexpr (kConvert) {
         if (!d_prepared) d_converted = need(cpoints, (size_t)n * gather_stride<FD>());
       }
-      XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(buckets, (size_t)p.W * p.B * sizeof(XYZZ<FD>));
+      XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(bucketsS[sl], (size_t)p.W * p.B * sizeof(XYZZ<FD>));
       const Staged st = accumulate_pairs(sl, p, d_coefs, coef_is_fr, d_points_in, d_prepared, d_converted, d_buckets);
+      // Early tail (round 4): a caller that keeps large MSMs in flight gets the head merge and EVERY reduction pass of this MSM on the
+      // tail stream, so that the next MSM's conversion and sort -- memory-bound -- start right behind this accumulation instead of
+      // behind the merge and the widest pass (VALU-bound additions, 0.16 ms at 2^20).  What those stages read is per slot (bstartS,
+      // maxcountS, bucketsS); the next accumulation still waits for the end of the wide passes (wide_wait), so nothing of this tail
+      // competes with an accumulation for wave slots (which is what sank round 3's version for small MSMs, section 5 of DESIGN.md).
+      if (early_tail_applies(p)) {
+        bk.tail_wait();    // (the previous tail ended long ago: it ran beside this accumulation)
+        bk.tail_begin();
+      }
       merge_buckets(sl, p, st);
       reduce_buckets(sl, p, d_buckets);
     } catch (const OutOfDeviceMemory&) {
       return release_slot(sl);
     }
     return sl;
+  }
+  // from ~2^19 pairs on, and only for a caller that is pipelining (the other slot is busy)
+  bool early_tail_applies(const MsmPlan& p) const {
+    static const int mode = getenv("CTT_HIP_MSM_EARLY_TAIL") ? atoi(getenv("CTT_HIP_MSM_EARLY_TAIL")) : 1;   // 0 off, 1 automatic, 2 whenever pipelining
+    if (mode == 0 || opt.early_tail == 0) return false;
+    const bool pipelining = slots[0].busy && slots[1].busy;
+    if (!pipelining) return false;
+    return mode >= 2 || opt.early_tail >= 2 || (uint64_t)p.nent * (uint64_t)p.W >= (1ull << 23);
   }
   // a submit that ran out of device memory: what it enqueued so far runs to its end on buffers that stay valid (a buffer is
   // only ever freed by need(), and hipFree waits for the device); the slot is free again.  Returns the error value -2.
@@ -791,10 +812,10 @@ struct MsmEngine {
     bk.stage_begin(sl, ST_TOTAL);
     const MsmPlan p0 = make_plan(largest, C::BITS, o);   // the largest slice sizes the workspace
     const size_t set = (size_t)p0.W * p0.B;
-    XYZZ<FD>* d_sets = (XYZZ<FD>*)need(buckets, (size_t)nch * set * sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_sets = (XYZZ<FD>*)need(bucketsS[sl], (size_t)nch * set * sizeof(XYZZ<FD>));
     void* d_conv_all = nullptr;
     if constexpr (kConvert) d_conv_all = need(cpoints, (size_t)n * gather_stride<FD>());
-    reserve_stage1(p0, coef_is_fr);
+    reserve_stage1(sl, p0, coef_is_fr);
     MsmPlan plast = p0;
     Staged st_prev{};
     MsmPlan p_prev = p0;
@@ -876,10 +897,10 @@ struct MsmEngine {
       point_stride = (uint32_t)sizeof(Affine<F>);
     }
     uint32_t* d_entries = (uint32_t*)need(entries, (size_t)n * 4);
-    uint32_t* d_bstart = (uint32_t*)need(bstart, 8);
-    uint32_t* d_maxcount = (uint32_t*)need(maxcount, 256);
+    uint32_t* d_bstart = (uint32_t*)need(bstartS[0], 8);
+    uint32_t* d_maxcount = (uint32_t*)need(maxcountS[0], 256);
     bk.launch_iota(d_entries, n, d_bstart, d_maxcount);
-    XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(buckets, sizeof(XYZZ<FD>));
+    XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(bucketsS[0], sizeof(XYZZ<FD>));
     bk.memset0(d_buckets, sizeof(XYZZ<FD>));
     XYZZ<FD>* d_heads = (XYZZ<FD>*)need(heads, (size_t)G * sizeof(XYZZ<FD>));
     XYZZ<FD>* d_tails = (XYZZ<FD>*)need(tails, (size_t)G * sizeof(XYZZ<FD>));

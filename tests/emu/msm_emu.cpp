@@ -29,6 +29,7 @@ struct EmuBackend {
   void tail_begin() {}
   void tail_end() {}
   void tail_wait() {}
+  bool tail_forked() const { return false; }
   void wide_mark() {}
   void wide_wait() {}
   void stage_chunk(int) {}
