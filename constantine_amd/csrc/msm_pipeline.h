@@ -733,13 +733,19 @@ struct MsmEngine {
     }
     return sl;
   }
-  // from ~2^19 pairs on, and only for a caller that is pipelining (the other slot is busy)
+  // Only for a caller that is pipelining (the other slot is busy), from ~2^18 pairs on, and while the accumulation is shorter than ~6 ms.
+  // Measured on one box, ms per MSM with two in flight, off / on, three repetitions (profiles/early_tail_r04.txt): BLS12-381 G1 2^19
+  // 1.70 / 1.63, 2^20 2.90 / 2.81 (-3.1 %), BN254 2^20 1.62 / 1.58, 2^22 5.39 / 5.25, Pallas 2^20 1.46 / 1.40 (-3.9 %), 2^18 1.011 / 0.998;
+  // but BLS12-381 G1 2^22 10.5 / 10.6 and G2 2^20 9.45 / 9.49: with a 8-10 ms accumulation the 0.16 ms are 1.5 % at best and the sort
+  // (0.5 ms at 2^22) running beside the widest pass loses more than the overlap gives.
   bool early_tail_applies(const MsmPlan& p) const {
     static const int mode = getenv("CTT_HIP_MSM_EARLY_TAIL") ? atoi(getenv("CTT_HIP_MSM_EARLY_TAIL")) : 1;   // 0 off, 1 automatic, 2 whenever pipelining
     if (mode == 0 || opt.early_tail == 0) return false;
     const bool pipelining = slots[0].busy && slots[1].busy;
     if (!pipelining) return false;
-    return mode >= 2 || opt.early_tail >= 2 || (uint64_t)p.nent * (uint64_t)p.W >= (1ull << 23);
+    if (mode >= 2 || opt.early_tail >= 2) return true;
+    const double additions = (double)p.nent * (double)p.W;
+    return additions >= (double)(1u << 22) && additions * opt.acc_ns < 6.0e6;
   }
   // a submit that ran out of device memory: what it enqueued so far runs to its end on buffers that stay valid (a buffer is
   // only ever freed by need(), and hipFree waits for the device); the slot is free again.  Returns the error value -2.
