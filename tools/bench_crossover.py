@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where the GPU takes over from the CPU (INTEGRATION.md part B's CttHipMinPoints): for N = 2^6 .. 2^16 BLS12-381 G1 pairs, the host-pointer
-call of the drop-in symbol (PCIe included, what a Constantine caller gets), the device-resident blocking call, and the CPU port on this box's
-cores (oracle/msm_ref.cpp: a restatement, slower than Constantine -- its published 16-thread laptop figures are printed beside it).
-One JSON line per size."""
+call of the drop-in symbol (PCIe included, what a Constantine caller gets) and the device-resident blocking call, with Constantine's published
+16-thread laptop figures beside them.  The CPU port's side of the comparison is `python bench.py --cpu-only --log2n K` (the one place outside tests/
+that runs the oracle): tools/collect_round.sh writes both.  One JSON line per size."""
 import json
 import os
 import statistics
@@ -13,13 +13,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from constantine_amd import CURVES, DeviceMsm, multiScalarMul_vartime_parallel  # noqa: E402
 from constantine_amd.synth import synth_scalars  # noqa: E402
-from oracle import cref  # noqa: E402
 
 PUBLISHED_MS = {10: 1.660, 12: 4.542, 14: 14.727, 15: 25.009, 16: 51.280}   # Ryzen 7 7840U, 16 threads
 name = "bls12_381_g1"
 info = CURVES[name]
-cref.build_native()
-threads = min(os.cpu_count() or 1, 32)
 eng = DeviceMsm(0)
 
 
@@ -42,8 +39,6 @@ for lg in (6, 8, 10, 11, 12, 13, 14, 16):
     d_s = torch.from_numpy(sc).cuda()
     host = med(lambda: multiScalarMul_vartime_parallel(None, name, sc, pts, coord="jac"), 30)
     dev = med(lambda: eng.msm(name, d_s, d, n, coord="aff"), 30)
-    cpu1 = med(lambda: cref.msm(name, sc, pts, nthreads=1), 3 if lg >= 14 else 5)
-    cpuN = med(lambda: cref.msm(name, sc, pts, nthreads=threads), 3 if lg >= 14 else 5)
-    print(json.dumps({"log2n": lg, "gpu_hostptr_ms": round(host, 4), "gpu_device_resident_ms": round(dev, 4), "cpu_port_1_thread_ms": round(cpu1, 3),
-                      f"cpu_port_{threads}_threads_ms": round(cpuN, 3), "constantine_published_16_threads_ms_other_hw": PUBLISHED_MS.get(lg)}), flush=True)
+    print(json.dumps({"log2n": lg, "gpu_hostptr_ms": round(host, 4), "gpu_device_resident_ms": round(dev, 4),
+                      "constantine_published_16_threads_ms_other_hw": PUBLISHED_MS.get(lg)}), flush=True)
 eng.close()
