@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTT_MSM_HIP_LIB") or os.path.join(HERE, "libctt_msm_hip.so")
 
 _lib = None
-ABI_VERSION = 7  # ctt_hip_msm_abi_version() of the library this package was written against
+ABI_VERSION = 8  # ctt_hip_msm_abi_version() of the library this package was written against
 
 
 class HipLibraryMissing(RuntimeError):
@@ -34,7 +34,8 @@ def exported_symbols():
              "ctt_hip_msm_host", "ctt_hip_msm_available",
              # part 3: the MSM's callers under the reference's names + their host-only pieces
              "ctt_eth_kzg_context_new", "ctt_eth_kzg_context_delete", "ctt_eth_kzg_blob_to_kzg_commitment", "ctt_eth_kzg_compute_kzg_proof",
-             "ctt_eth_kzg_compute_blob_kzg_proof", "ctt_eth_evm_bls12381_g1msm", "ctt_eth_evm_bls12381_g2msm",
+             "ctt_eth_kzg_compute_blob_kzg_proof", "ctt_eth_kzg_blob_to_kzg_commitment_parallel", "ctt_eth_kzg_compute_kzg_proof_parallel",
+             "ctt_eth_kzg_compute_blob_kzg_proof_parallel", "ctt_eth_evm_bls12381_g1msm", "ctt_eth_evm_bls12381_g2msm",
              "ctt_hip_eth_kzg_context_from_srs", "ctt_hip_sha256", "ctt_hip_bls12_381_g1_decompress", "ctt_hip_bls12_381_g1_compress",
              "ctt_hip_eth_kzg_blob_to_scalars", "ctt_hip_eth_kzg_challenge", "ctt_hip_eth_kzg_quotient_host"]
     return syms
@@ -113,6 +114,10 @@ def lib():
         L.ctt_eth_kzg_compute_kzg_proof.restype = u8
         L.ctt_eth_kzg_compute_blob_kzg_proof.argtypes = [vp, vp, vp, vp]
         L.ctt_eth_kzg_compute_blob_kzg_proof.restype = u8
+        for nm in ("ctt_eth_kzg_blob_to_kzg_commitment", "ctt_eth_kzg_compute_kzg_proof", "ctt_eth_kzg_compute_blob_kzg_proof"):
+            par = getattr(L, nm + "_parallel")       # (tp, ...) -- ethereum_eip4844_kzg_parallel.h
+            par.argtypes = [vp] + list(getattr(L, nm).argtypes)
+            par.restype = u8
         for nm in ("ctt_eth_evm_bls12381_g1msm", "ctt_eth_evm_bls12381_g2msm"):
             getattr(L, nm).argtypes = [vp, sz, vp, sz]
             getattr(L, nm).restype = u8

@@ -103,14 +103,14 @@ struct GatherLds {
     qinf = r.w[gather_flag_offset<F>() / 4u] != 0u;
   }
 };
-template <class F>
+template <class F, bool INTO = false>
 __global__ void __launch_bounds__(ACCUM_BLOCK, (sizeof(XYZZ<F>) > 256 ? 1 : CTT_ACCUM_WAVES)) k_accum(AccumArgs<F> a) {
   if constexpr (F::UNSAT && !IsFp2<F>::value) {
     __shared__ uint4 stage[GatherLds<F>::NCH][ACCUM_BLOCK];
     GatherLds<F> gq{stage};
-    accum_body<F, GatherLds<F>>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gq);
+    accum_body<F, GatherLds<F>, INTO>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gq);
   } else {
-    accum_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+    accum_body<F, INTO>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
   }
 }
 template <class F>
@@ -130,10 +130,6 @@ template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_pyr(PyrArgs<F> a, uint32_t ntasks) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < ntasks) pyr_body<F>(a, blockIdx.y, t);
-}
-template <class F>
-__global__ void __launch_bounds__(EC_BLOCK) k_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
-  bucket_sum_body<F>(sets, nsets, set_elems, blockIdx.x * blockDim.x + threadIdx.x);
 }
 static __global__ void k_iota(uint32_t* entries, uint32_t n, uint32_t* bucket_start, uint32_t* maxcount) {
   iota_body(entries, n, bucket_start, maxcount, blockIdx.x * blockDim.x + threadIdx.x);
@@ -510,6 +506,20 @@ struct HipBackend {
     HIP_CHECK(hipEventRecord(ev_copy, cpy));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_copy, 0));
   }
+  // The slices of a host-pointer MSM are copied by a thread of their own (MsmEngine::submit_host): a pageable hipMemcpyAsync
+  // returns when its last byte has left, and a caller that enqueues the ~15 launches of slice i between the copies of slices i and
+  // i+1 leaves the link idle for ~0.1 ms per slice (profiles/hostptr_timeline_r04.txt).  The uploader records ev_slice[i] behind the
+  // copies of slice i and raises a host flag; the submitting thread waits for the flag (an event that has not been recorded yet
+  // would not hold the stream) and lets the main stream wait for the event.
+  static constexpr bool THREADED_UPLOAD = true;
+  hipEvent_t ev_slice[MAX_CHUNKS] = {};
+  void (*uploader_hook)(int device) = nullptr;   // (msm_engine.hip: the NUMA pinning of the uploader thread)
+  void uploader_begin() {
+    HIP_CHECK(hipSetDevice(device));
+    if (uploader_hook) uploader_hook(device);
+  }
+  void h2d_slice_done(uint32_t i) { HIP_CHECK(hipEventRecord(ev_slice[i], cpy)); }
+  void h2d_slice_wait(uint32_t i) { HIP_CHECK(hipStreamWaitEvent(stream, ev_slice[i], 0)); }
   void d2h_async(int slot, void* dst_pinned, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst_pinned, src, b, hipMemcpyDeviceToHost, cur()));
     HIP_CHECK(hipEventRecord(ev_done[slot], cur()));
@@ -567,7 +577,7 @@ struct HipBackend {
   template <class F>
   uint32_t resident_lanes() {
     int nb = 0;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_accum<F>, ACCUM_BLOCK, 0));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_accum<F, false>, ACCUM_BLOCK, 0));
     if (nb < 1) nb = 1;
     return (uint32_t)nb * ACCUM_BLOCK * (uint32_t)num_cu;
   }
@@ -593,9 +603,11 @@ struct HipBackend {
   }
   void sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
   void launch_digits_sort(const SortArgs& a);  // msm_engine.hip
+  // into: the bucket set holds earlier sums that the runs continue (a later slice of a host-pointer MSM, accum_body_xyzz)
   template <class F>
-  void launch_accum(const AccumArgs<F>& a, uint32_t W) {
-    hipLaunchKernelGGL(k_accum<F>, grid2(a.G, ACCUM_BLOCK, W), dim3(ACCUM_BLOCK), 0, stream, a);
+  void launch_accum(const AccumArgs<F>& a, uint32_t W, bool into = false) {
+    if (into) hipLaunchKernelGGL((k_accum<F, true>), grid2(a.G, ACCUM_BLOCK, W), dim3(ACCUM_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((k_accum<F, false>), grid2(a.G, ACCUM_BLOCK, W), dim3(ACCUM_BLOCK), 0, stream, a);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
@@ -619,11 +631,6 @@ struct HipBackend {
     hipLaunchKernelGGL(k_merge_finish<F>, dim3(W), dim3(RED_BLOCK), 0, cur(), a, first_d);
     HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_merge_final<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a);
-    HIP_CHECK(hipGetLastError());
-  }
-  template <class F>
-  void launch_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
-    hipLaunchKernelGGL(k_bucket_sum<F>, grid1(set_elems, EC_BLOCK), dim3(EC_BLOCK), 0, stream, sets, nsets, set_elems);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
@@ -803,59 +810,11 @@ struct CurveImpl {
                        (const Affine<F>*)d_points, n, (uint8_t*)d_ok);
     HIP_CHECK(hipGetLastError());
   }
-  // [|x|]P for the BLS12-381 parameter |x| = 0xd201000000010000 (pow_bls12_381_abs_x, named/constants/bls12_381_subgroups.nim:20-45):
-  // 63 doublings and 5 additions
-  template <class HF>
-  static XYZZ<HF> bls12_381_mul_abs_x(const Affine<HF>& P) {
-    XYZZ<HF> r = xyzz_mdbl<HF>(P.x, P.y);
-    xyzz_madd<HF>(r, P, false);                                   // 0b11
-    static const int runs[5] = {2, 3, 9, 32, 16};
-    for (int k = 0; k < 5; k++) {
-      for (int i = 0; i < runs[k]; i++) r = xyzz_dbl<HF>(r);
-      if (k < 4) xyzz_madd<HF>(r, P, false);                      // 0b1101, 0b1101001, ...0000001, ...00000001, then 16 doublings
-    }
-    return r;
-  }
-  // points first, first + step, ... < n (one host thread's share)
+  // points first, first + step, ... < n (one host thread's share); the same templates as the kernel, over the host's 64-bit field
   static void subgroup_check_host(const void* pts_aff, size_t first, size_t step, size_t n, uint8_t* ok) {
     using HF = typename Engine::HF;
-    using Fr = typename C::Fr;
     const Affine<HF>* p = (const Affine<HF>*)pts_aff;
-    if constexpr (std::is_same<C, Bls12381G1>::value) {
-      // The reference's own test for this group (isInSubgroup, bls12_381_subgroups.nim:170-191; Scott, eprint 2021/1130): P is in G1 iff
-      // phi(P) = [-x^2]P with phi(X, Y) = (beta X, Y), beta = BLS12_381_cubicRootOfUnity_mod_p -- 126 doublings and 10 additions
-      // instead of 255 and ~128.  tests/test_batch_ops.py checks it against [r]P = neutral on points inside and outside the subgroup.
-      static const HF beta = []() {
-        // 0x5f19672fdf76ce51ba69c6076a0f77eaddb3a93be6f89688de17d813620a00022e01fffffffefffe (named/constants/bls12_381_endomorphisms.nim:18-19)
-        static const uint64_t w[6] = {0x2e01fffffffefffeull, 0xde17d813620a0002ull, 0xddb3a93be6f89688ull, 0xba69c6076a0f77eaull, 0x5f19672fdf76ce51ull, 0x0ull};
-        HF b, r2;
-        for (int i = 0; i < HF::N; i++) {
-          b.l[i] = w[i];
-          r2.l[i] = (uint64_t)HF::Params::R2[2 * i] | ((uint64_t)HF::Params::R2[2 * i + 1] << 32);
-        }
-        return HF::mul(b, r2);
-      }();
-      for (size_t j = first; j < n; j += step) {
-        const Affine<HF> P = p[j];
-        if (P.is_inf()) { ok[j] = 1; continue; }
-        const Affine<HF> t0 = xyzz_to_affine<HF>(bls12_381_mul_abs_x<HF>(P));          // [|x|]P
-        if (t0.is_inf()) { ok[j] = 0; continue; }
-        const XYZZ<HF> t1 = bls12_381_mul_abs_x<HF>(t0);                               // [x^2]P; the test is phi(P) == -t1
-        if (t1.is_inf()) { ok[j] = 0; continue; }
-        const bool same_x = HF::eq(t1.x, HF::mul(HF::mul(P.x, beta), t1.zz));
-        const bool opp_y = HF::add(t1.y, HF::mul(P.y, t1.zzz)).is_zero();
-        ok[j] = (same_x && opp_y) ? 1 : 0;
-      }
-      return;
-    }
-    for (size_t j = first; j < n; j += step) {
-      XYZZ<HF> r = XYZZ<HF>::inf();
-      for (int i = 32 * Fr::N - 1; i >= 0; i--) {
-        r = xyzz_dbl<HF>(r);
-        if ((Fr::Params::P[i >> 5] >> (i & 31)) & 1u) xyzz_madd<HF>(r, p[j], false);
-      }
-      ok[j] = r.is_inf() ? 1 : 0;
-    }
+    for (size_t j = first; j < n; j += step) ok[j] = point_in_subgroup<C, HF>(p[j]) ? 1 : 0;
   }
   static int fr_quotient(HipBackend* bk, const void* d_poly, const void* d_dom, const void* z_host, uint32_t n, void* d_work,
                          void* d_q, void* y_host) {

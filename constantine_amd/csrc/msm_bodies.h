@@ -211,7 +211,7 @@ struct AccumArgs {
   const uint32_t* bucket_start;  // [W][B+1] exclusive prefix of bucket sizes; [B] = entries in window
   const void* points;            // affine points, `point_stride` bytes apart
   uint32_t point_stride;
-  XYZZ<F>* buckets;              // [W][B]   (pre-zeroed = neutral)
+  XYZZ<F>* buckets;              // [W][B]   (pre-zeroed = neutral; INTO: the sums so far)
   XYZZ<F>* heads;                // [W][G]
   XYZZ<F>* tails;                // [W][G]
   uint32_t* hkey;                // [W][G]
@@ -267,7 +267,12 @@ struct BucketWalk {
   }
 };
 
-template <class F, class G>
+// INTO (a later slice of a host-pointer MSM, MsmEngine::submit_host): the bucket set already holds the sums of the earlier slices.
+// A lane that STARTS a bucket inside its range -- exactly one lane per non-empty bucket does -- begins with the stored sum
+// instead of an empty accumulator: a 2-line load per bucket where a separate bucket set per slice costs a full addition per
+// bucket and slice afterwards (rounds 2-3: k_bucket_sum).  Heads (runs that began in an earlier lane) start empty as always, and the head /
+// tail merge is unchanged: the tail piece it starts from carries the stored sum.
+template <class F, class G, bool INTO = false>
 CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq) {
   if (g >= a.G) return;
   const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
@@ -288,6 +293,12 @@ CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq
   // the accumulator's "neutral" state lives in a flag (xyzz_madd_flag): nothing to zero when a run is flushed
   XYZZ<F> acc;
   bool empty = true;
+  if constexpr (INTO) {
+    if (!bw.head0) {
+      acc = a.buckets[(uint64_t)w * a.B + bw.b];
+      empty = acc.is_inf();
+    }
+  }
   const uint32_t* ent = a.entries + (uint64_t)w * a.N;
   auto record = [&](uint32_t e) {
     return (const char*)__builtin_assume_aligned((const char*)a.points + (uint64_t)(e & 0x7fffffffu) * a.point_stride, 16);
@@ -312,6 +323,10 @@ CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq
       first_run = false;
       empty = true;
       bw.next(pos);
+      if constexpr (INTO) {
+        acc = a.buckets[(uint64_t)w * a.B + bw.b];
+        empty = acc.is_inf();
+      }
     }
     gq.request(record(e1));                                        // entry pos+1 (the last one again at the end)
     const uint32_t e2 = ent[pos + 2 < p1 ? pos + 2 : plast];
@@ -340,7 +355,7 @@ CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq
 // Records are read on demand here: this kernel lives at the edge of its register file (483 of 512 registers, one wave per
 // SIMD), and the pipelined loop order of accum_body_xyzz -- the record collected before the bucket boundary is handled --
 // measured 11 % slower for BLS12-381 G2 on the same box (9.47 -> 10.53 ms at 2^20), with the LDS gather or without.
-template <class F, class Z>
+template <class F, class Z, bool INTO = false>
 CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
   if (g >= a.G) return;
   const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
@@ -378,6 +393,16 @@ CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
     }
     return r;
   };
+  auto resume = [&](uint32_t bb) {   // INTO: start from the stored sum of the earlier slices (see accum_body_xyzz)
+    const XYZZ<F> r = a.buckets[(uint64_t)w * a.B + bb];
+    empty = r.is_inf();
+    X = r.x;
+    Y = r.y;
+    z.put(r.zz, r.zzz);
+  };
+  if constexpr (INTO) {
+    if (!(bs[b] < p0)) resume(b);
+  }
   const uint32_t* ent = a.entries + (uint64_t)w * a.N;
   for (uint32_t pos = p0; pos < p1; pos++) {
     if (pos == bend) {
@@ -393,6 +418,7 @@ CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
       b++;
       while (bs[b + 1] == pos) b++;  // skip empty buckets; terminates because pos < nw
       bend = bs[b + 1];
+      if constexpr (INTO) resume(b);
     }
     uint32_t e = ent[pos];
     const char* rec = (const char*)__builtin_assume_aligned((const char*)a.points + (uint64_t)(e & 0x7fffffffu) * a.point_stride, 16);
@@ -415,19 +441,19 @@ CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
   a.hkey[slot] = hk;
   a.tkey[slot] = tk;
 }
-template <class F, class G>
+template <class F, class G, bool INTO = false>
 CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq) {
   if constexpr (IsFp2<F>::value && F::UNSAT) {
     ZInRegs<F> z;
-    accum_body_z<F, ZInRegs<F>>(a, w, g, z);
+    accum_body_z<F, ZInRegs<F>, INTO>(a, w, g, z);
   } else {
-    accum_body_xyzz<F, G>(a, w, g, gq);
+    accum_body_xyzz<F, G, INTO>(a, w, g, gq);
   }
 }
-template <class F>
+template <class F, bool INTO = false>
 CTT_HD void accum_body(const AccumArgs<F>& a, uint32_t w, uint32_t g) {
   GatherDirect<F> gq;
-  accum_body<F, GatherDirect<F>>(a, w, g, gq);
+  accum_body<F, GatherDirect<F>, INTO>(a, w, g, gq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -517,20 +543,6 @@ CTT_HD void merge_finish_body(const MergeArgs<F>& a, uint32_t w, uint32_t first_
     for (uint32_t g = lane; g < a.G; g += nlanes) merge_step_body<F>(a, w, g, d);
     sync();
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Sum of the bucket sets of a host-pointer MSM uploaded in slices (MsmEngine::submit_host): sets[0][i] += sets[k][i].
-// ---------------------------------------------------------------------------------------------
-template <class F>
-CTT_HD void bucket_sum_body(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems, uint32_t i) {
-  if (i >= set_elems) return;
-  XYZZ<F> acc = sets[i];
-  for (uint32_t k = 1; k < nsets; k++) {
-    XYZZ<F> y = sets[(uint64_t)k * set_elems + i];
-    acc = xyzz_add_inl<F>(acc, y);
-  }
-  sets[i] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -828,23 +840,91 @@ CTT_HD FD dev_field_probe(int op, const FD& x, const FD& y) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Subgroup check of many points at once: ok[j] = ([r]P_j is the neutral element), r = the curve order (the modulus of C::Fr).
+// Subgroup check of many points at once: ok[j] = (P_j has order r), r = the curve order (the modulus of C::Fr) -- [r]P_j = neutral.
 // What the reference's deserialisers do per point (e.g. ethereum_evm_precompiles.nim fromRawCoords -> isInSubgroup); here the
 // MSM's callers (EIP-2537 G1MSM/G2MSM, KZG commitments) validate all their points with one launch: the bits of r are the same
 // for every lane, so the double-and-add is convergent.
 // ---------------------------------------------------------------------------------------------
+// BLS12-381 has the reference's endomorphism tests instead (isInSubgroup, named/constants/bls12_381_subgroups.nim:170-207; Scott,
+// eprint 2021/1130):  G1: phi(P) = [-x^2]P with phi(X, Y) = (beta X, Y), beta a primitive cube root of unity mod p
+// (BLS12_381_cubicRootOfUnity_mod_p, bls12_381_endomorphisms.nim:18-19) -- 126 doublings and 10 additions;  G2: psi(P) = [x]P with the
+// untwist-Frobenius-twist psi(X, Y) = (conj(X) c2, conj(Y) c3), c2 = (1/(1+i))^((p-1)/3), c3 = (1/(1+i))^((p-1)/2)
+// (= BLS12_381_FrobeniusPsi_psi1_coef2 / _coef3, bls12_381_frobenius.nim:136-145; derived in Python) -- 63 doublings and 5 additions;
+// against 255 doublings and ~128 additions.  x = -0xd201000000010000.  Host (Fp64) and device (Fp) run the same templates;
+// tests/test_abi_symbols.py and tests/test_batch_ops.py hold them against [r]P = neutral on points inside and outside the subgroups.
+struct Bls12381Endo {   // Montgomery residues (R = 2^384), 32-bit words, least significant first
+  static constexpr uint32_t BETA[12] = {0x798a64e8u, 0x30f1361bu, 0x7ece5a2au, 0xf3b8ddabu, 0xc61577f7u, 0x16a8ca3au, 0x74fd029bu, 0xc26a2ff8u, 0x60701c6eu, 0x3636b766u, 0x241b6160u, 0x051ba4abu};
+  static constexpr uint32_t PSI_C2_1[12] = {0x867545c3u, 0x890dc9e4u, 0x3285a5d5u, 0x2af32253u, 0x309b7e2cu, 0x50880866u, 0x7e881024u, 0xa20d1b8cu, 0xe2db9068u, 0x14e4f04fu, 0x1564853au, 0x14e56d3fu};
+  static constexpr uint32_t PSI_C3_0[12] = {0xa55c9ad1u, 0x3e2f585du, 0x86c18183u, 0x4294213du, 0x8b623732u, 0x382844c8u, 0x19103e18u, 0x92ad2afdu, 0xac7cf0b9u, 0x1d794e4fu, 0x7d825ec8u, 0x0bd592fcu};
+  static constexpr uint32_t PSI_C3_1[12] = {0x5aa30fdau, 0x7bcfa7a2u, 0x2a927e7cu, 0xdc17dec1u, 0x6b4ebef1u, 0x2f088dd8u, 0xda74d4a7u, 0xd1ca2087u, 0x96cebc1du, 0x2da25966u, 0xbbfd87d2u, 0x0e2b7eedu};
+};
+// a base-field element from 12 words: Fp (32-bit limbs) or the host's Fp64 (64-bit limbs)
+template <class B>
+CTT_HD B bls12_381_fp_from_words(const uint32_t* w) {
+  B r;
+  if constexpr (sizeof(B) / B::N == 8) {
+    for (int i = 0; i < B::N; i++) r.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+  } else {
+    for (int i = 0; i < B::N; i++) r.l[i] = w[i];
+  }
+  return r;
+}
+// [|x|]P, |x| = 0xd201000000010000 (pow_bls12_381_abs_x, bls12_381_subgroups.nim:20-45): 63 doublings and 5 additions
+template <class FF>
+CTT_HD XYZZ<FF> bls12_381_mul_abs_x(const Affine<FF>& P) {
+  XYZZ<FF> r = xyzz_mdbl<FF>(P.x, P.y);
+  xyzz_madd<FF>(r, P, false);                                   // 0b11
+  const int runs[5] = {2, 3, 9, 32, 16};
+  for (int k = 0; k < 5; k++) {
+    for (int i = 0; i < runs[k]; i++) r = xyzz_dbl<FF>(r);
+    if (k < 4) xyzz_madd<FF>(r, P, false);                      // 0b1101, 0b1101001, ...0000001, ...00000001, then 16 doublings
+  }
+  return r;
+}
+// is t (extended Jacobian) the negative of the affine point (qx, qy)?
+template <class FF>
+CTT_HD bool xyzz_is_neg_of(const XYZZ<FF>& t, const FF& qx, const FF& qy) {
+  if (t.is_inf()) return false;
+  return FF::eq(t.x, FF::mul(qx, t.zz)) & FF::add(t.y, FF::mul(qy, t.zzz)).is_zero();
+}
+template <class FF>
+CTT_HD bool bls12_381_g1_in_subgroup(const Affine<FF>& P) {
+  if (P.is_inf()) return true;
+  const Affine<FF> t0 = xyzz_to_affine<FF>(bls12_381_mul_abs_x<FF>(P));   // [|x|]P
+  if (t0.is_inf()) return false;
+  const XYZZ<FF> t1 = bls12_381_mul_abs_x<FF>(t0);                        // [x^2]P; the test is phi(P) == -t1
+  return xyzz_is_neg_of<FF>(t1, FF::mul(P.x, bls12_381_fp_from_words<FF>(Bls12381Endo::BETA)), P.y);
+}
+template <class FF2>
+CTT_HD bool bls12_381_g2_in_subgroup(const Affine<FF2>& P) {
+  using B = typename FF2::Base;
+  if (P.is_inf()) return true;
+  const XYZZ<FF2> t = bls12_381_mul_abs_x<FF2>(P);                        // [|x|]P = -[x]P; the test is psi(P) == -t
+  const FF2 c2{B::zero(), bls12_381_fp_from_words<B>(Bls12381Endo::PSI_C2_1)};
+  const FF2 c3{bls12_381_fp_from_words<B>(Bls12381Endo::PSI_C3_0), bls12_381_fp_from_words<B>(Bls12381Endo::PSI_C3_1)};
+  return xyzz_is_neg_of<FF2>(t, FF2::mul(FF2{P.x.c0, B::neg(P.x.c1)}, c2), FF2::mul(FF2{P.y.c0, B::neg(P.y.c1)}, c3));
+}
+// one point, any curve: the curve's fast test where there is one, else [r]P = neutral
+template <class C, class FF>
+CTT_HD bool point_in_subgroup(const Affine<FF>& P) {
+  using Fr = typename C::Fr;
+  if constexpr (C::ID == 0) {
+    return bls12_381_g1_in_subgroup<FF>(P);
+  } else if constexpr (C::ID == 1) {
+    return bls12_381_g2_in_subgroup<FF>(P);
+  } else {
+    XYZZ<FF> r = XYZZ<FF>::inf();
+    for (int i = 32 * Fr::N - 1; i >= 0; i--) {
+      r = xyzz_dbl<FF>(r);
+      if ((Fr::Params::P[i >> 5] >> (i & 31)) & 1u) xyzz_madd<FF>(r, P, false);
+    }
+    return r.is_inf();
+  }
+}
 template <class C>
 CTT_HD void subgroup_check_body(const Affine<typename C::F>* pts, uint32_t n, uint8_t* ok, uint32_t j) {
-  using F = typename C::F;
-  using Fr = typename C::Fr;
   if (j >= n) return;
-  const Affine<F> P = pts[j];
-  XYZZ<F> r = XYZZ<F>::inf();
-  for (int i = 32 * Fr::N - 1; i >= 0; i--) {
-    r = xyzz_dbl<F>(r);
-    if ((Fr::Params::P[i >> 5] >> (i & 31)) & 1u) xyzz_madd<F>(r, P, false);
-  }
-  ok[j] = r.is_inf() ? 1 : 0;
+  ok[j] = point_in_subgroup<C, typename C::F>(pts[j]) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -344,6 +346,12 @@ static inline XYZZ<F> combine_groups(const XYZZ<F>* s, int W, const WinLayout& L
 // Stage indices for timings
 enum { ST_DIGITS = 0, ST_SORT, ST_ACCUM, ST_MERGE, ST_REDUCE, ST_TOTAL, ST_COUNT };
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
+
 template <class C, class BK>
 struct MsmEngine {
   using F = typename C::F;    // reference representation (C API)
@@ -487,7 +495,7 @@ struct MsmEngine {
     need(tkey, W * p.G * 4);
   }
   Staged accumulate_pairs(int sl, const MsmPlan& p, const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in,
-                          const void* d_prepared, void* d_converted, XYZZ<FD>* d_buckets) {
+                          const void* d_prepared, void* d_converted, XYZZ<FD>* d_buckets, bool into = false) {
     const uint32_t n = p.n, W = p.W, B = p.B;
     bk.stage_begin(sl, ST_DIGITS);
     const uint32_t* d_scalars = d_coefs;
@@ -542,7 +550,8 @@ struct MsmEngine {
     // a slower box: reduce span 2.4 ms, the pipeline slower than the serial order).  Worst case this is the serial order.
     // (the bucket sets are cleared before that wait: the previous MSM read them in its first reduction pass, which is ahead
     // of this point on the main stream, and its tail does not touch them)
-    bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
+    // (into: a later slice of a host-pointer MSM continues the sums of the earlier slices, accum_body_xyzz)
+    if (!into) bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
     // When the accumulate grid leaves wave slots free (submit() sees to that for a caller that keeps MSMs in flight: 1/16 of the
     // slots up to 2^17 pairs, 1/64 of them while that costs less than half the wait), the previous tail's narrow passes run next to it, and the wait moves to the
     // start of this MSM's reduction (reduce_buckets), the first kernel that writes what the tail still reads.
@@ -556,7 +565,7 @@ struct MsmEngine {
     st.d_hkey = (uint32_t*)need(hkey, (size_t)W * p.G * 4);
     st.d_tkey = (uint32_t*)need(tkey, (size_t)W * p.G * 4);
     AccumArgs<FD> aa{d_entries, st.d_bstart, d_points, point_stride, d_buckets, st.d_heads, st.d_tails, st.d_hkey, st.d_tkey, p.nent, B, p.K, p.G};
-    bk.template launch_accum<FD>(aa, W);
+    bk.template launch_accum<FD>(aa, W, into);
     bk.stage_end(sl, ST_ACCUM);
     return st;
   }
@@ -762,43 +771,30 @@ struct MsmEngine {
   // into its own bucket set (one owner per bucket per launch, no atomics); the sets are summed before the one bucket
   // reduction.  d_stage_coefs / d_stage_points: device staging for all n pairs (caller-owned).  Blocking on the copies,
   // asynchronous from the last accumulation on; returns the slot, or -1 when both slots are in flight.
-  static uint32_t host_chunks(uint32_t n, int want) {
-    // automatic (measured, profiles/hostptr_r02.txt: BLS12-381 G1, ms per call with 1 slice / 4 slices -- 2^16: 1.22 / 1.85,
-    // 2^18: 2.31 / 2.79 (2 slices: 2.35), 2^20: 6.37 / 5.05, 2^22: 22.8 / 15.4): only the first slice's upload is exposed,
-    // every extra slice costs one more sort launch sequence and one more addition per bucket.
-    // An explicit request is honoured.
-    // Round 3 (no host wait between the slices any more, profiles/hostptr_r03.txt): 2^18 1.93 (2 slices) / 2.03 (3), 2^20 6.08 (1) /
-    // 5.00 (2) / 4.49 (3) / 4.58 (4), 2^22 22.3 / 17.2 / 15.5 / 14.4.
-    // Round 4 (profiles/hostptr_r04.txt, gpurun_out/r4a): 2^18 2.01 (1) / 1.89 (2) / 1.95 (3): two slices from 2^18 on (round 3: from 3 * 2^17).
-    uint32_t cch = want > 0 ? (uint32_t)want : (n >= (1u << 21) ? 4u : n >= (3u << 18) ? 3u : n >= (1u << 18) ? 2u : 1u);
-    if (cch > 8) cch = 8;
-    if (cch > n) cch = n;
-    return cch < 1 ? 1 : cch;
-  }
-  int submit_host(const void* h_coefs, bool coef_is_fr, const void* h_points, uint32_t n, void* d_stage_coefs,
-                  void* d_stage_points, int want_chunks) {
-    const int sl = claim_slot(n);
-    if (sl < 0 || n == 0) return sl;
-    const uint32_t nch = host_chunks(n, want_chunks);
-    // Slice sizes.  The GPU needs gpu_ns per pair (windows x the curve's accumulate time + sort), the pageable copy copy_ns
-    // (56 GB/s measured, profiles/h2d_overlap_r02.jsonl).  GPU-bound (BLS12-381: 2.5 against 2.3 ns; G2): only the first
-    // slice's upload is exposed, and slice i+1 may be as much larger than slice i as the GPU takes longer over a pair than the
-    // link does -- weights 1, g, g^2, ... with g <= 1.4.  Copy-bound (the 254/255-bit curves: 1.2 against 1.7 ns -- the
-    // Halo2-ZAL configuration): the whole copy is on the critical path whatever the slicing and what is exposed is the LAST
-    // slice's GPU work, so the slices shrink instead (round 2 grew them for every curve: 39 % of a BN254 2^22 call's pairs
-    // were accumulated after the last byte had arrived, 10.4 ms per call against 7.2 ms of copy).  Every slice a multiple of 64
-    // pairs except the last.
-    const double gpu_ns = (double)((C::BITS + 16) / 16) * C::ACC_NS * 1.12, copy_ns = (double)(32 + sizeof(Affine<F>)) / 56.0;
-    double growth = gpu_ns / copy_ns;
-    if (growth > 1.4) growth = 1.4;
-    if (growth < 0.7) growth = 0.7;
-    std::vector<uint32_t> bound(nch + 1, 0);
-    {
+  // The slices of a host-pointer call: bound[0] = 0 < bound[1] < ... < bound[nch] = n.
+  // Model (round 4; fitted to the timeline in profiles/hostptr_timeline_r04.txt): the link moves a pair in copy_ns (56 GB/s pageable,
+  // profiles/h2d_overlap_r02.jsonl), the copies of slice i end at C_i = copy_ns * (pairs up to and including slice i); the GPU takes
+  // gpu_ns per pair (windows x the curve's accumulate time) plus a fixed fix_ns per slice (conversion, the sort's launch chain, the
+  // head merge: ~0.19 ms whatever the slice holds) and finishes slice i at F_i = max(F_(i-1), C_i) + gpu_ns * s_i + fix_ns.  Sizes
+  // s_i ~ r^i; the slice count (1..6, or the caller's) and r (0.5..2.5) are the pair with the smallest F_last, a further slice
+  // having to buy 3 %.  GPU-bound curves (BLS12-381 G1: 2.5 against 2.3 ns per pair; G2) come out with a small first slice -- its
+  // copy is the only one exposed -- and growing ones after it (2^20 BLS12-381 G1 pairs: 24 / 32 / 44 %, G2: 12 / 27 / 61 %); copy-bound
+  // curves (the 254/255-bit ones, 1.2 against 1.7 ns -- the Halo2-ZAL configuration) with shrinking ones, since what is exposed there
+  // is the last slice's GPU work (BN254 2^22: 24 / 20 / 17 / 15 / 13 / 11 %).  Small calls stay whole: one slice up to 2^17 pairs, two at
+  // 2^18.  Rounds 2-3 took weights g^i with g = gpu_ns / copy_ns clamped to [0.7, 1.4] and 2 / 3 / 4 slices from 2^18 / 3 * 2^18 / 2^21.
+  // Measured, same box, old / new (gpurun_out/r4l -> profiles/hostptr_r04.txt, ms per call): BLS12-381 G1 2^20 4.47-4.58 / 4.36-4.58 (level),
+  // 2^22 14.0-14.2 / 13.3-13.8, 2^24 52.1 / 49.6-50.1; G2 2^20 12.8-13.0 / 12.1-12.2; BN254 2^22 9.33-9.35 / 8.64-8.75; Pallas 2^20 2.87 / 2.86.
+  // Every slice a multiple of 64 pairs except the last.  An explicit slice count is honoured.
+  static constexpr double HOST_SLICE_FIX_NS = 1.9e5;
+  static std::vector<uint32_t> host_slices(uint32_t n, int want) {
+    const double gpu_ns = (double)((C::BITS + 16) / 16) * C::ACC_NS * 1.09, copy_ns = (double)(32 + sizeof(Affine<F>)) / 56.0;
+    auto sizes = [&](uint32_t nch, double r) {
+      std::vector<uint32_t> bound(nch + 1, 0);
       double wsum = 0, w = 1;
-      for (uint32_t i = 0; i < nch; i++, w *= growth) wsum += w;
+      for (uint32_t i = 0; i < nch; i++, w *= r) wsum += w;
       double acc = 0;
       w = 1;
-      for (uint32_t i = 0; i + 1 < nch; i++, w *= growth) {
+      for (uint32_t i = 0; i + 1 < nch; i++, w *= r) {
         acc += w;
         uint64_t b = (uint64_t)((double)n * acc / wsum);
         b &= ~63ull;
@@ -807,7 +803,46 @@ struct MsmEngine {
         bound[i + 1] = (uint32_t)b;
       }
       bound[nch] = n;
+      return bound;
+    };
+    auto finish_ns = [&](const std::vector<uint32_t>& bound) {
+      double f = 0;
+      for (size_t i = 0; i + 1 < bound.size(); i++) {
+        const double c = copy_ns * (double)bound[i + 1];
+        f = (f > c ? f : c) + gpu_ns * (double)(bound[i + 1] - bound[i]) + HOST_SLICE_FIX_NS;
+      }
+      return f;
+    };
+    uint32_t lo = 1, hi = 6;
+    if (want > 0) lo = hi = (uint32_t)(want > 8 ? 8 : want);
+    if (hi > n) hi = n;
+    if (lo > hi) lo = hi;
+    std::vector<uint32_t> best;
+    double best_ns = 0;
+    for (uint32_t nch = lo; nch <= hi; nch++) {
+      std::vector<uint32_t> b = sizes(nch, 1.0);
+      double t = finish_ns(b);
+      for (int k = 0; k <= 40 && nch > 1; k++) {
+        const std::vector<uint32_t> cand = sizes(nch, 0.5 + 0.05 * k);
+        const double tc = finish_ns(cand);
+        if (tc < t) {
+          t = tc;
+          b = cand;
+        }
+      }
+      if (best.empty() || t < best_ns * 0.97) {   // (a further slice has to buy 3 %: small slices accumulate less efficiently than the model says)
+        best_ns = t;
+        best = b;
+      }
     }
+    return best;
+  }
+  int submit_host(const void* h_coefs, bool coef_is_fr, const void* h_points, uint32_t n, void* d_stage_coefs,
+                  void* d_stage_points, int want_chunks) {
+    const int sl = claim_slot(n);
+    if (sl < 0 || n == 0) return sl;
+    const std::vector<uint32_t> bound = host_slices(n, want_chunks);
+    const uint32_t nch = (uint32_t)bound.size() - 1;
     uint32_t largest = 0;
     for (uint32_t i = 0; i < nch; i++) largest = bound[i + 1] - bound[i] > largest ? bound[i + 1] - bound[i] : largest;
     opt.acc_ns = C::ACC_NS;
@@ -817,22 +852,53 @@ struct MsmEngine {
     try {
     bk.stage_begin(sl, ST_TOTAL);
     const MsmPlan p0 = make_plan(largest, C::BITS, o);   // the largest slice sizes the workspace
-    const size_t set = (size_t)p0.W * p0.B;
-    XYZZ<FD>* d_sets = (XYZZ<FD>*)need(bucketsS[sl], (size_t)nch * set * sizeof(XYZZ<FD>));
+    // ONE bucket set for all slices (round 4): the accumulation of slice i > 0 continues the stored sums (k_accum<FD, true>).  Rounds
+    // 2-3 gave every slice its own set and added the sets afterwards: a full addition per bucket and slice, 0.24 ms of a 4.6 ms call
+    // at 2^20 BLS12-381 G1 in three slices (k_bucket_sum, profiles/hostptr_timeline_r04.txt).
+    XYZZ<FD>* d_sets = (XYZZ<FD>*)need(bucketsS[sl], (size_t)p0.W * p0.B * sizeof(XYZZ<FD>));
     void* d_conv_all = nullptr;
     if constexpr (kConvert) d_conv_all = need(cpoints, (size_t)n * gather_stride<FD>());
     reserve_stage1(sl, p0, coef_is_fr);
     MsmPlan plast = p0;
     Staged st_prev{};
     MsmPlan p_prev = p0;
+    auto upload = [&](uint32_t i) {
+      const uint32_t start = bound[i], cnt = bound[i + 1] - bound[i];
+      bk.h2d((uint32_t*)d_stage_coefs + (size_t)start * 8, (const char*)h_coefs + (size_t)start * 32, (size_t)cnt * 32);
+      bk.h2d((Affine<F>*)d_stage_points + start, (const char*)h_points + (size_t)start * sizeof(Affine<F>), (size_t)cnt * sizeof(Affine<F>));
+    };
+    // Several slices: a thread of its own issues the copies back to back (HipBackend::h2d_slice_done has the reason), this one
+    // enqueues slice i's kernels as soon as slice i has been handed to the link.
+    const bool threaded = BK::THREADED_UPLOAD && nch > 2;   // (two slices: one gap of ~0.1 ms against a thread start of about as much -- measured: 2^18 1.85 ms without, 1.93 with)
+    std::atomic<uint32_t> uploaded{0};
+    std::thread uploader;
+    struct Joiner {
+      std::thread& t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{uploader};                          // (also on the out-of-memory exit: the staging buffers outlive this call)
+    if (threaded)
+      uploader = std::thread([&]() {
+        bk.uploader_begin();
+        for (uint32_t i = 0; i < nch; i++) {
+          upload(i);
+          bk.h2d_slice_done(i);
+          uploaded.store(i + 1, std::memory_order_release);
+        }
+      });
     for (uint32_t i = 0; i < nch; i++) {
       const uint32_t start = bound[i], cnt = bound[i + 1] - bound[i];
       bk.stage_chunk((int)i);   // stage events of this slice (the stage times of the call are the sums over its slices)
       uint32_t* d_c = (uint32_t*)d_stage_coefs + (size_t)start * 8;
       Affine<F>* d_p = (Affine<F>*)d_stage_points + start;
-      bk.h2d(d_c, (const char*)h_coefs + (size_t)start * 32, (size_t)cnt * 32);                   // the GPU works on slice i-1 meanwhile
-      bk.h2d(d_p, (const char*)h_points + (size_t)start * sizeof(Affine<F>), (size_t)cnt * sizeof(Affine<F>));
-      bk.h2d_done();                                                                              // main stream waits for the copies
+      if (threaded) {
+        for (uint32_t spin = 0; uploaded.load(std::memory_order_acquire) <= i; spin++) {
+          if (spin < 20000u) cpu_relax(); else std::this_thread::yield();
+        }
+        bk.h2d_slice_wait(i);                                                                     // main stream waits for the copies
+      } else {
+        upload(i);
+        bk.h2d_done();
+      }
       if (i > 0) {   // slice i-1's merge goes in front of slice i's kernels (shared workspace)
         bk.stage_chunk((int)i - 1);
         merge_buckets(sl, p_prev, st_prev);
@@ -840,12 +906,11 @@ struct MsmEngine {
       }
       const MsmPlan p = make_plan(cnt, C::BITS, o);
       void* d_conv = kConvert ? (void*)((char*)d_conv_all + (size_t)start * gather_stride<FD>()) : nullptr;
-      st_prev = accumulate_pairs(sl, p, d_c, coef_is_fr, d_p, nullptr, d_conv, d_sets + (size_t)i * set);
+      st_prev = accumulate_pairs(sl, p, d_c, coef_is_fr, d_p, nullptr, d_conv, d_sets, /*into=*/i > 0);
       p_prev = p;
       plast = p;
     }
     merge_buckets(sl, p_prev, st_prev);
-    if (nch > 1) bk.template launch_bucket_sum<FD>(d_sets, nch, (uint32_t)set);
     plast.n = n;
     slots[sl].plan = plast;
     last_plan = plast;

@@ -685,6 +685,20 @@ uint8_t ctt_eth_kzg_compute_blob_kzg_proof(const ctt_eth_kzg_context_struct* ctx
   return KZG_Success;
 }
 
+// the _parallel forms (ethereum_eip4844_kzg_parallel.h:40,61,73): the thread pool is not used, as in the MSM's _parallel symbols
+uint8_t ctt_eth_kzg_blob_to_kzg_commitment_parallel(const void* /*tp*/, const ctt_eth_kzg_context_struct* ctx, uint8_t dst[48],
+                                                    const uint8_t* blob) {
+  return ctt_eth_kzg_blob_to_kzg_commitment(ctx, dst, blob);
+}
+uint8_t ctt_eth_kzg_compute_kzg_proof_parallel(const void* /*tp*/, const ctt_eth_kzg_context_struct* ctx, uint8_t proof[48],
+                                               uint8_t y_be[32], const uint8_t* blob, const uint8_t z_be[32]) {
+  return ctt_eth_kzg_compute_kzg_proof(ctx, proof, y_be, blob, z_be);
+}
+uint8_t ctt_eth_kzg_compute_blob_kzg_proof_parallel(const void* /*tp*/, const ctt_eth_kzg_context_struct* ctx, uint8_t proof[48],
+                                                    const uint8_t* blob, const uint8_t commitment[48]) {
+  return ctt_eth_kzg_compute_blob_kzg_proof(ctx, proof, blob, commitment);
+}
+
 // ---- EIP-2537 BLS12_G1MSM / BLS12_G2MSM (ethereum_evm_precompiles.h:386,419) -------------------------------------------
 // parseRawUint: a 64-byte big-endian field element, top 16 bytes zero, below p
 static bool evm_fp(const uint8_t* b64, FpH& out) {

@@ -122,6 +122,31 @@ def compute_blob_kzg_proof(ctx: EthereumKZGContext, blob: bytes, commitment_byte
     return bytes(proof)
 
 
+# the reference's _parallel forms (ethereum_eip4844_kzg_parallel.nim: `tp` first): the same GPU path, the thread pool is not used
+def blob_to_kzg_commitment_parallel(tp, ctx: EthereumKZGContext, blob: bytes) -> bytes:
+    if len(blob) != BYTES_PER_BLOB:
+        raise KzgError(cttEthKzgStatus.cttEthKzg_InputsLengthsMismatch)
+    out = (ctypes.c_uint8 * 48)()
+    _check(ctx.L.ctt_eth_kzg_blob_to_kzg_commitment_parallel(tp, ctx.handle, out, _buf(blob)))
+    return bytes(out)
+
+
+def compute_kzg_proof_parallel(tp, ctx: EthereumKZGContext, blob: bytes, z_bytes: bytes):
+    if len(blob) != BYTES_PER_BLOB or len(z_bytes) != 32:
+        raise KzgError(cttEthKzgStatus.cttEthKzg_InputsLengthsMismatch)
+    proof, y = (ctypes.c_uint8 * 48)(), (ctypes.c_uint8 * 32)()
+    _check(ctx.L.ctt_eth_kzg_compute_kzg_proof_parallel(tp, ctx.handle, proof, y, _buf(blob), _buf(z_bytes)))
+    return bytes(proof), bytes(y)
+
+
+def compute_blob_kzg_proof_parallel(tp, ctx: EthereumKZGContext, blob: bytes, commitment_bytes: bytes) -> bytes:
+    if len(blob) != BYTES_PER_BLOB or len(commitment_bytes) != 48:
+        raise KzgError(cttEthKzgStatus.cttEthKzg_InputsLengthsMismatch)
+    proof = (ctypes.c_uint8 * 48)()
+    _check(ctx.L.ctt_eth_kzg_compute_blob_kzg_proof_parallel(tp, ctx.handle, proof, _buf(blob), _buf(commitment_bytes)))
+    return bytes(proof)
+
+
 # ---- the host-only pieces of the library (no GPU), as the tests reach them ----------------------------------------------------
 def g1_decompress(b48: bytes) -> bytes:
     """ctt_hip_bls12_381_g1_decompress: 48 compressed bytes -> affine Montgomery {x, y} (96 bytes, (0,0) = neutral)."""

@@ -246,9 +246,11 @@ int ctt_hip_sum_reduce(ctt_hip_msm_ctx* ctx, int curve, int out_kind, void* r, c
  * batchAffine(_vartime) (ec_shortweierstrass_batch_ops.nim:44-345).  Both arrays on the host (on_device = 0) or both
  * in HBM (1).  Blocking. */
 int ctt_hip_batch_affine(ctt_hip_msm_ctx* ctx, int curve, int src_kind, void* dst, const void* src, size_t n, int on_device);
-/* ok[i] = 1 when [r]points[i] is the neutral element (r = the curve order): the subgroup check that the MSM's callers run
- * on deserialised points (eth_evm_bls12381_g1msm / g2msm, ethereum_evm_precompiles.nim:894-975; KZG commitments), for all n
- * points in one launch.  points: affine, host (points_on_device = 0) or device memory; ok: n bytes of host memory. */
+/* ok[i] = 1 when points[i] has order r (r = the curve order; the neutral passes): the subgroup check that the MSM's callers
+ * run on deserialised points (eth_evm_bls12381_g1msm / g2msm, ethereum_evm_precompiles.nim:894-975; KZG commitments), for all n
+ * points at once.  BLS12-381: the reference's endomorphism tests (isInSubgroup, named/constants/bls12_381_subgroups.nim:170-207);
+ * other curves: [r]P = neutral.  Up to 64 host-resident points (256 for BLS12-381) are checked on host threads, more -- or
+ * device-resident ones -- in one launch.  points: affine, host (points_on_device = 0) or device memory; ok: n bytes of host memory. */
 int ctt_hip_subgroup_check(ctt_hip_msm_ctx* ctx, int curve, uint8_t* ok, const void* points, size_t n, int points_on_device);
 /* Quotient polynomial of a KZG opening over the scalar field of `curve`, in evaluation form: the Fr-side work of kzg_prove
  * (constantine/commitments/kzg.nim:204-223 -> getQuotientPoly).  d_poly: n canonical scalars (the MSM's coefficient format),
@@ -304,6 +306,15 @@ ctt_eth_kzg_status ctt_eth_kzg_compute_kzg_proof(const ctt_eth_kzg_context* ctx,
                                                  const ctt_eth_kzg_opening_challenge* z);
 ctt_eth_kzg_status ctt_eth_kzg_compute_blob_kzg_proof(const ctt_eth_kzg_context* ctx, ctt_eth_kzg_proof* proof,
                                                       const ctt_eth_kzg_blob* blob, const ctt_eth_kzg_commitment* commitment);
+/* include/constantine/protocols/ethereum_eip4844_kzg_parallel.h:40, :61, :73 -- the thread pool is accepted and not used */
+ctt_eth_kzg_status ctt_eth_kzg_blob_to_kzg_commitment_parallel(const ctt_threadpool* tp, const ctt_eth_kzg_context* ctx,
+                                                               ctt_eth_kzg_commitment* dst, const ctt_eth_kzg_blob* blob);
+ctt_eth_kzg_status ctt_eth_kzg_compute_kzg_proof_parallel(const ctt_threadpool* tp, const ctt_eth_kzg_context* ctx,
+                                                          ctt_eth_kzg_proof* proof, ctt_eth_kzg_eval_at_challenge* y,
+                                                          const ctt_eth_kzg_blob* blob, const ctt_eth_kzg_opening_challenge* z);
+ctt_eth_kzg_status ctt_eth_kzg_compute_blob_kzg_proof_parallel(const ctt_threadpool* tp, const ctt_eth_kzg_context* ctx,
+                                                               ctt_eth_kzg_proof* proof, const ctt_eth_kzg_blob* blob,
+                                                               const ctt_eth_kzg_commitment* commitment);
 ctt_evm_status ctt_eth_evm_bls12381_g1msm(ctt_byte* r, size_t r_len, const ctt_byte* inputs, size_t inputs_len);
 ctt_evm_status ctt_eth_evm_bls12381_g2msm(ctt_byte* r, size_t r_len, const ctt_byte* inputs, size_t inputs_len);
 

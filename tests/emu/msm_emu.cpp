@@ -36,10 +36,10 @@ struct EmuBackend {
   void d2h_sync(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void h2d(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void h2d_done() {}
-  template <class F>
-  void launch_bucket_sum(XYZZ<F>* sets, uint32_t nsets, uint32_t set_elems) {
-    for (uint32_t i = 0; i < set_elems; i++) bucket_sum_body<F>(sets, nsets, set_elems, i);
-  }
+  static constexpr bool THREADED_UPLOAD = true;   // (the slices of submit_host are copied by a thread here too: same code path)
+  void uploader_begin() {}
+  void h2d_slice_done(uint32_t) {}
+  void h2d_slice_wait(uint32_t) {}
   void launch_iota(uint32_t* entries, uint32_t n, uint32_t* bstart, uint32_t* maxcount) {
     for (uint32_t j = 0; j < (n ? n : 1); j++) iota_body(entries, n, bstart, maxcount, j);
   }
@@ -120,8 +120,11 @@ struct EmuBackend {
     }
   }
   template <class F>
-  void launch_accum(const AccumArgs<F>& a, uint32_t W) {
-    for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) accum_body<F>(a, w, g);
+  void launch_accum(const AccumArgs<F>& a, uint32_t W, bool into = false) {
+    for (uint32_t w = 0; w < W; w++)
+      for (uint32_t g = 0; g < a.G; g++) {
+        if (into) accum_body<F, true>(a, w, g); else accum_body<F, false>(a, w, g);
+      }
   }
   template <class F>
   void launch_merge_tail(const MergeArgs<F>& a, uint32_t W) {

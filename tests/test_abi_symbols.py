@@ -92,9 +92,9 @@ def test_host_mirror_argument_checks():
 
 
 def test_subgroup_check_of_a_few_host_points_runs_on_the_host():
-    """ctt_hip_subgroup_check with <= 64 host-resident points never touches the GPU (one GPU lane needs 6.5 ms for [r]P): the generic
-    [r]P = neutral on the host for every curve, and for BLS12-381 G1 the reference's endomorphism test phi(P) = [-x^2]P
-    (bls12_381_subgroups.nim:170-191).  Against the big-integer oracle on subgroup points, curve points outside the subgroup, a point
+    """ctt_hip_subgroup_check with <= 64 host-resident points (256 for BLS12-381) never touches the GPU (one GPU lane needs 6.5 ms for [r]P): the generic
+    [r]P = neutral on the host for every curve, and for BLS12-381 the reference's endomorphism tests phi(P) = [-x^2]P for G1 and
+    psi(P) = [x]P for G2 (bls12_381_subgroups.nim:170-207).  Against the big-integer oracle on subgroup points, curve points outside the subgroup, a point
     of order 3 and the neutral."""
     import random
     from constantine_amd.msm import subgroup_check
@@ -115,6 +115,16 @@ def test_subgroup_check_of_a_few_host_points_runs_on_the_host():
                 if y * y % p == y2:
                     outside.append((x, y))
             outside.append((0, 2))             # x = 0: a point of order 3
+        if name == "bls12_381_g2":
+            # a point of the twist outside G2: the reference's EIP-2537 failure vector, its multiples, and its sums with G2 points
+            import json
+            from tests import _golden
+            doc = json.load(open(os.path.join(_golden.HERE, "eip2537_multiexp.json")))
+            raw = bytes.fromhex(next(inp for _, inp, err in doc["g2_fail"] if "subgroup" in err))[:256]
+            c = [int.from_bytes(raw[64 * i:64 * i + 64], "big") for i in range(4)]
+            Q = ((c[0], c[1]), (c[2], c[3]))
+            assert curve.is_on_curve(Q)
+            outside = [Q, curve.scalar_mul(2, Q), curve.scalar_mul(5, Q), curve.add(Q, inside[0]), curve.add(curve.scalar_mul(7, Q), inside[1])]
         pts = inside + outside + [None]
         want = [curve.scalar_mul(curve.order, P) is None for P in pts]
         assert want[:6] == [True] * 6 and want[-1] is True

@@ -231,15 +231,21 @@ def test_fr_coefs_entry(name):
 
 @pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_snarks_g1", "bls12_381_g2"])
 def test_host_pointer_form_uploads_in_slices(name):
-    """MsmEngine::submit_host: the pairs arrive in slices, every slice is sorted and accumulated into its own bucket set,
-    the sets are summed before the one bucket reduction -- same element for any number of slices (1, 2, 3, 8; ragged
-    slice sizes; slices that leave whole buckets empty; Fr Montgomery coefficients)."""
+    """MsmEngine::submit_host: the pairs arrive in slices, every slice is sorted on its own and accumulated INTO the one bucket set
+    (accum_body<F, INTO = true>: a run continues the sum the earlier slices stored) -- same element for any number of slices (1, 2,
+    3, 8; ragged slice sizes; slices that leave whole buckets empty; a pair that meets its own copy, and one that meets its
+    negative, in a later slice: the stored sum is doubled / becomes the neutral; Fr Montgomery coefficients)."""
     curve = po.CURVES[name]
     n = 1201 if curve.F.degree == 1 else 150
     pts = cref.gen_points(name, 501, n)
     sc = cref.synth_scalars(502, n, curve.scalar_bits)
     sc[:40] = sc[0]                      # one heavy bucket per window that lives in the first slice only
     pts[7] = 0                           # a neutral point
+    # the same (scalar, point) again in the last slice, and a (scalar, -point): every window's bucket of pair 45 is re-entered with the
+    # stored P and doubled; pair 46's holds P, then P - P
+    sc[n - 3], pts[n - 3] = sc[45], pts[45]
+    sc[n - 2] = sc[46]
+    pts[n - 2] = curve.points_to_array([curve.neg(curve.aff_from_bytes(bytes(pts[46])))])[0]
     expect, _ = cref.msm(name, sc, pts)
     for chunks, c in ((1, 0), (2, 0), (3, 5), (8, 0), (2, 11)):
         out, used = emu.msm_host(name, sc, pts, c=c, chunks=chunks)

@@ -77,8 +77,38 @@ def test_status_is_that_of_the_first_offending_point():
         with pytest.raises(evm.EvmError) as e:
             evm.eth_evm_bls12381_g1msm(b"".join(p + k for p in pts))
         assert e.value.status.name == want
-    # the batched check itself, all six curves: subgroup points pass, the neutral passes
+    # the batched check itself, all six curves: subgroup points pass, the neutral passes (65 points: the GPU launch for the curves
+    # without an endomorphism test, 300: for BLS12-381 too)
     for name in cref.AFF_BYTES:
-        pts = cref.gen_points(name, 3, 65)
+        pts = cref.gen_points(name, 3, 300 if name.startswith("bls12_381") else 65)
         pts[7] = 0
         assert subgroup_check(name, pts).all(), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bls12_381_g2"])
+def test_subgroup_check_kernel_rejects_points_outside_the_subgroup(name):
+    """The GPU form of the reference's endomorphism tests (k_subgroup_check -> bls12_381_g1/g2_in_subgroup, msm_bodies.h;
+    bls12_381_subgroups.nim:170-207) on more points than the host path takes: points of the curve outside the subgroup (the
+    reference's failure vectors, their multiples, their sums with subgroup points), a point of order 3, the neutral, subgroup
+    points -- against [r]P = neutral by the big-integer oracle."""
+    from constantine_amd.msm import subgroup_check
+    from oracle import cref
+    from oracle import pyoracle as po
+    curve = po.CURVES[name]
+    group = name[-2:]
+    rec = 128 if group == "g1" else 256
+    raw = bytes.fromhex(next(inp for _, inp, err in DOC[group + "_fail"] if "subgroup" in err))[:rec]
+    c = [int.from_bytes(raw[64 * i:64 * i + 64], "big") for i in range(rec // 64)]
+    Q = (c[0], c[1]) if group == "g1" else ((c[0], c[1]), (c[2], c[3]))
+    assert curve.is_on_curve(Q)
+    inside = [curve.aff_from_bytes(bytes(b)) for b in cref.gen_points(name, 21, 5)]
+    distinct = inside + [Q, curve.scalar_mul(2, Q), curve.scalar_mul(5, Q), curve.add(Q, inside[0]),
+                         curve.add(curve.scalar_mul(7, Q), inside[1]), None]
+    if group == "g1":
+        distinct.append((0, 2))                                   # x = 0: order 3
+    want = [curve.scalar_mul(curve.order, P) is None for P in distinct]
+    assert want[:5] == [True] * 5 and not any(want[5:10]) and want[10] is True
+    reps = 400 // len(distinct) + 1                               # > 256 points: the launch, not the host path
+    got = subgroup_check(name, curve.points_to_array(distinct * reps))
+    assert [bool(v) for v in got] == want * reps

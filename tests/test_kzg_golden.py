@@ -175,6 +175,8 @@ def test_blob_to_kzg_commitment_on_gpu():
                         kzg.blob_to_kzg_commitment(ctx, blob)
                 else:
                     assert kzg.blob_to_kzg_commitment(ctx, blob) == com, name
+                    if table:   # the _parallel symbol (ethereum_eip4844_kzg_parallel.h:40): same path, thread pool unused
+                        assert kzg.blob_to_kzg_commitment_parallel(None, ctx, blob) == com, name
             assert n == 11
         finally:
             ctx.delete()
@@ -194,12 +196,14 @@ def test_compute_kzg_proof_vectors_on_gpu():
                     kzg.compute_kzg_proof(ctx, blob, zb)
             else:
                 assert kzg.compute_kzg_proof(ctx, blob, zb) == res, case
+                assert kzg.compute_kzg_proof_parallel(None, ctx, blob, zb) == res, case
         for case, blob, com, res in cases["compute_blob_kzg_proof"]:
             if res is None:
                 with pytest.raises(kzg.KzgError):
                     kzg.compute_blob_kzg_proof(ctx, blob, com)
             else:
                 assert kzg.compute_blob_kzg_proof(ctx, blob, com) == res, case
+                assert kzg.compute_blob_kzg_proof_parallel(None, ctx, blob, com) == res, case
     finally:
         ctx.delete()
 

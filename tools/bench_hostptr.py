@@ -23,7 +23,7 @@ for lg in (16, 18, 20, 22):
     pts = d.cpu().numpy()
     eng.close()
     sc = synth_scalars(6, n, 255)
-    for chunks in (0, 1, 2, 3, 4):
+    for chunks in (0, 1, 2, 3, 4, 5, 6):
         _lib.lib().ctt_hip_msm_set_option(None, b"chunks", chunks)
         multiScalarMul_vartime_parallel(None, name, sc, pts, coord="jac")
         reps = 10
