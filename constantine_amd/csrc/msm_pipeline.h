@@ -907,6 +907,10 @@ struct MsmEngine {
         bk.stage_chunk((int)i);
       }
       const MsmPlan p = make_plan(cnt, C::BITS, o);
+      if (p.W != p0.W || p.B != p0.B) {   // (the slices share one bucket set: same windows, same buckets -- o.c is fixed above)
+        fprintf(stderr, "[ctt_msm] FATAL: slice %u of a host-pointer MSM planned %u windows of %u buckets, the call %u of %u\n", i, p.W, p.B, p0.W, p0.B);
+        abort();
+      }
       void* d_conv = kConvert ? (void*)((char*)d_conv_all + (size_t)start * gather_stride<FD>()) : nullptr;
       st_prev = accumulate_pairs(sl, p, d_c, coef_is_fr, d_p, nullptr, d_conv, d_sets, /*into=*/i > 0);
       p_prev = p;
