@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -871,22 +872,27 @@ struct MsmEngine {
     };
     // Several slices: a thread of its own issues the copies back to back (HipBackend::h2d_slice_done has the reason), this one
     // enqueues slice i's kernels as soon as slice i has been handed to the link.
-    const bool threaded = BK::THREADED_UPLOAD && nch > 2;   // (two slices: one gap of ~0.1 ms against a thread start of about as much -- measured: 2^18 1.85 ms without, 1.93 with)
+    bool threaded = BK::THREADED_UPLOAD && nch > 2;   // (two slices: one gap of ~0.1 ms against a thread start of about as much -- measured: 2^18 1.85 ms without, 1.93 with)
     std::atomic<uint32_t> uploaded{0};
     std::thread uploader;
     struct Joiner {
       std::thread& t;
       ~Joiner() { if (t.joinable()) t.join(); }
     } joiner{uploader};                          // (also on the out-of-memory exit: the staging buffers outlive this call)
-    if (threaded)
-      uploader = std::thread([&]() {
-        bk.uploader_begin();
-        for (uint32_t i = 0; i < nch; i++) {
-          upload(i);
-          bk.h2d_slice_done(i);
-          uploaded.store(i + 1, std::memory_order_release);
-        }
-      });
+    if (threaded) {
+      try {
+        uploader = std::thread([&]() {
+          bk.uploader_begin();
+          for (uint32_t i = 0; i < nch; i++) {
+            upload(i);
+            bk.h2d_slice_done(i);
+            uploaded.store(i + 1, std::memory_order_release);
+          }
+        });
+      } catch (const std::system_error&) {
+        threaded = false;   // (no thread to be had: this one copies, as with two slices)
+      }
+    }
     for (uint32_t i = 0; i < nch; i++) {
       const uint32_t start = bound[i], cnt = bound[i + 1] - bound[i];
       bk.stage_chunk((int)i);   // stage events of this slice (the stage times of the call are the sums over its slices)

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -739,11 +740,17 @@ static int evm_validate_and_msm(int curve, void* r_aff, const void* coefs, const
     return parse[bad];
   }
   int check_rc = 0;
-  const bool beside = n <= 256;   // (the host side of ctt_hip_subgroup_check; above it the check is a launch on the context the MSM uses:
+  bool beside = n <= 256;   // (the host side of ctt_hip_subgroup_check; above it the check is a launch on the context the MSM uses:
                                   //  measured slower side by side than one after the other, 512 G2 pairs 9.0 against 4.8 ms)
   std::thread check;
-  if (beside) check = std::thread([&]() { check_rc = ctt_hip_subgroup_check(nullptr, curve, ok.data(), pts, n, 0); });
-  else {
+  if (beside) {
+    try {
+      check = std::thread([&]() { check_rc = ctt_hip_subgroup_check(nullptr, curve, ok.data(), pts, n, 0); });
+    } catch (const std::system_error&) {
+      beside = false;   // (no thread to be had: one after the other)
+    }
+  }
+  if (!beside) {
     check_rc = ctt_hip_subgroup_check(nullptr, curve, ok.data(), pts, n, 0);
     if (check_rc != 0) abort();
     for (size_t i = 0; i < n; i++)
