@@ -484,6 +484,14 @@ def main():
                           f"{cores} threads on a {budget}-CPU cgroup quota ({os.cpu_count()} logical CPUs visible, {cpu_model()}); {flags}",
             }
             out["parity_vs_oracle_on_sample"] = bool(bytes(got) == bytes(exp))
+            # the WHOLE timed workload, without the port: the points are [s_i]G with known s_i, so the MSM is [sum a_i s_i mod r]G --
+            # an exact integer dot product and one scalar multiplication of the big-integer oracle (cref.msm_by_discrete_logs)
+            from oracle import pyoracle as po
+            t1 = time.perf_counter()
+            want = cref.msm_by_discrete_logs(curve, seed, scal, first=first)
+            out["parity_full_size_vs_discrete_logs"] = bool(po.CURVES[curve].aff_from_bytes(bytes(res)) == want)
+            out["parity_full_size_note"] = (f"the timed loop's result for all 2^{args.log2n} pairs against [sum a_i s_i mod r]G "
+                                            f"(big-integer oracle, {time.perf_counter() - t1:.1f} s; no bucket method involved)")
             tool = reference_toolchain()
             out["cpu_baseline"]["reference_toolchain"] = tool
             out["cpu_baseline"]["published_reference"] = [r for r in PUBLISHED_REFERENCE if r["curve"] == curve]

@@ -109,3 +109,39 @@ def synth_scalars(seed: int, n: int, bits: int, first: int = 0) -> np.ndarray:
     top = bits - 192
     z[:, 3] &= np.uint64((1 << top) - 1)
     return z.view(np.uint8).reshape(n, 32).copy()
+
+def gen_point_scalars(seed: int, n: int, first: int = 0) -> np.ndarray:
+    """The discrete logs of the synthetic points: gen_points(name, seed, n)[i] = [s_i]G with s_i = pyoracle.synth_scalar(seed ^ 0xA5A5..,
+    i, 128) | 1 (pyoracle.synth_point, msm_ref.cpp gen_points, msm_bodies.h gen_point_body).  (n, 16) u8, little-endian."""
+    idx = (np.arange(first, first + n, dtype=np.uint64)[:, None] * np.uint64(4) + np.arange(2, dtype=np.uint64)[None, :])
+    with np.errstate(over="ignore"):
+        x = idx + np.uint64((seed ^ 0xA5A5A5A5A5A5A5A5) & (2**64 - 1))
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    z[:, 0] |= np.uint64(1)
+    return z.view(np.uint8).reshape(n, 16).copy()
+
+
+def msm_by_discrete_logs(name: str, point_seed: int, scalars: np.ndarray, first: int = 0):
+    """MSM of the synthetic points gen_points(name, point_seed, n) without any elliptic-curve arithmetic but ONE scalar multiplication of
+    the big-integer oracle (pinned by the reference's scalar-mul vectors): sum a_i P_i = [sum a_i s_i mod r] G.  An answer for 2^20 .. 2^24
+    pairs that owes nothing to the C++ port (msm_ref.cpp) the GPU is otherwise compared with.  -> affine point of pyoracle (or None).
+    The dot product runs on 16-bit limbs as a float64 matrix product over blocks of 2^20 rows (a product < 2^32, any partial sum < 2^52:
+    exact whatever the order of summation)."""
+    from . import pyoracle as po
+    curve = po.CURVES[name]
+    sc = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+    n = sc.shape[0]
+    logs = gen_point_scalars(point_seed, n, first)
+    t = 0
+    for lo in range(0, n, 1 << 20):
+        a = sc[lo:lo + (1 << 20)].view("<u2").astype(np.float64)         # (m, 16)
+        b = logs[lo:lo + (1 << 20)].view("<u2").astype(np.float64)       # (m, 8)
+        m = a.T @ b                                                      # (16, 8): every partial sum < 2^52, exact in binary64
+        for j in range(16):
+            for k in range(8):
+                t += int(m[j, k]) << (16 * (j + k))
+    return curve.scalar_mul(t % curve.order, curve.gen)

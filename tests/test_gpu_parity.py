@@ -512,6 +512,9 @@ def _full_size(name, lg, dev, torch, seed=None):
     full = dev.msm(name, ds, dp, n, coord="aff")
     expect, _ = cref.msm(name, sc, dp.cpu().numpy(), nthreads=NT)
     assert bytes(expect) == bytes(full)
+    # independent of the C++ port: the points are [s_i]G with known s_i, so the MSM is [sum a_i s_i mod r]G -- one scalar
+    # multiplication of the big-integer oracle (pinned by the reference's vectors), no bucket method anywhere
+    assert curve.aff_from_bytes(bytes(full)) == cref.msm_by_discrete_logs(name, seed or (1000 + lg), sc)
     h = n // 2
     a = dev.msm(name, ds[:h], dp[:h], h, coord="aff")
     b = dev.msm(name, ds[h:], dp[h:], n - h, coord="aff")
@@ -571,6 +574,7 @@ def test_bls12_381_g1_2pow24_full_oracle(dev, torch_cuda):
     assert bytes(ec_sum_affine(name, np.stack(parts))) == bytes(full)
     expect, _ = cref.msm(name, sc, dp.cpu().numpy(), nthreads=NT)
     assert bytes(expect) == bytes(full)
+    assert po.CURVES[name].aff_from_bytes(bytes(full)) == cref.msm_by_discrete_logs(name, 2424, sc)   # (no port involved: _full_size)
 
 
 def test_bn254_g1_2pow22_zal_entry_full_oracle(dev, torch_cuda):
@@ -588,6 +592,7 @@ def test_bn254_g1_2pow22_zal_entry_full_oracle(dev, torch_cuda):
     mont = cref.synth_scalars(2223, n, 253)          # any 253-bit pattern is a valid Fr Montgomery residue (r > 2^253)
     can = cref.fr_from_mont(name, mont)              # the canonical scalars the entry point computes with
     expect = _aff(curve, cref.msm(name, can, pts, nthreads=NT)[0])
+    assert expect == cref.msm_by_discrete_logs(name, 2222, can)      # the port against the discrete-log identity (no bucket method)
     assert curve.prj_from_bytes(bytes(CttEngine(0).msm(mont, pts))) == expect
     # the device-resident path on the same pairs (what bench.py --curve bn254_snarks_g1 --log2n 22 times)
     assert _aff(curve, dev.msm(name, _to_dev(torch, mont), dp, n, coord="aff", fr_coefs=True)) == expect

@@ -89,6 +89,28 @@ def test_serial_equals_parallel_medium(name):
     assert bytes(a) == bytes(b) == bytes(c)
 
 
+@pytest.mark.parametrize("name,lg", [("bls12_381_g1", 17), ("bls12_381_g2", 14), ("bn254_snarks_g1", 17), ("bn254_snarks_g2", 14),
+                                     ("pallas", 16), ("vesta", 16)])
+def test_port_against_the_discrete_log_identity(name, lg):
+    """The C++ port at sizes pyoracle's bucket method cannot reach (the GPU tests compare with the port at 2^20 .. 2^24): the synthetic
+    points are [s_i]G with known s_i, so sum a_i P_i = [sum a_i s_i mod r]G -- big-integer arithmetic and ONE scalar multiplication
+    of the Python oracle, which the reference's own vectors pin (test_scalar_mul_kats).  Endomorphism path and plain path, threads."""
+    curve = po.CURVES[name]
+    n = (1 << lg) + 77
+    pts = cref.gen_points(name, 9000 + lg, n)
+    sc = cref.synth_scalars(9100 + lg, n, curve.scalar_bits)
+    sc[3] = 255                                     # a scalar above the bit width (all 256 bits set)
+    sc[4] = 0
+    want = cref.msm_by_discrete_logs(name, 9000 + lg, sc)
+    for nthreads in (1, 8):
+        out, _ = cref.msm(name, sc, pts, nthreads=nthreads)
+        assert _aff(curve, out) == want, (name, nthreads)
+    # a slice of the sequence (first > 0): what a rank of a sharded run generates
+    h = n // 3
+    out, _ = cref.msm(name, sc[h:], pts[h:])
+    assert _aff(curve, out) == cref.msm_by_discrete_logs(name, 9000 + lg, sc[h:], first=h)
+
+
 @pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_snarks_g1", "vesta"])
 def test_fr_roundtrip_and_value(name):
     curve = po.CURVES[name]
