@@ -133,6 +133,8 @@ def test_msm_medium_default_plan(name):
     expect, _ = cref.msm(name, sc, pts, nthreads=4)
     out, plan = emu.msm(name, sc, pts)
     assert bytes(out) == bytes(expect), plan
+    # and without the port: the points are [s_i]G with known s_i (cref.msm_by_discrete_logs, the big-integer oracle only)
+    assert curve.aff_from_bytes(bytes(out)) == cref.msm_by_discrete_logs(name, 13, sc)
     out, plan = emu.msm(name, sc, pts, S=3, K=12)
     assert bytes(out) == bytes(expect), plan
 

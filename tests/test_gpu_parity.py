@@ -625,16 +625,19 @@ def test_two_msms_in_flight(dev, torch_cuda):
 
 
 def test_host_symbols_upload_in_slices():
-    """The host-pointer symbols upload the pairs in slices underneath the accumulation, one bucket set per slice
-    (MsmEngine::submit_host): same element for 1, 2, 3, 4, 8 slices and for the automatic choice, ragged sizes."""
+    """The host-pointer symbols upload the pairs in slices underneath the accumulation (MsmEngine::submit_host; round 4: ONE bucket set,
+    k_accum<FD, INTO> continues the stored sums; from three slices on the copies come from a helper thread): same element for 1, 2,
+    3, 4, 8 slices and for the automatic choice, ragged sizes -- against the port and against the discrete-log identity."""
     from constantine_amd import _lib, multiScalarMul_vartime, multiScalarMul_vartime_parallel
     L = _lib.lib()
     try:
-        for name, n in (("bls12_381_g1", (1 << 20) + 3), ("bn254_snarks_g1", 300001), ("bls12_381_g2", 40000), ("pallas", 7)):
+        for name, n in (("bls12_381_g1", (1 << 20) + 3), ("bn254_snarks_g1", 300001), ("bls12_381_g2", 40000), ("bls12_381_g2", (1 << 17) + 5),
+                        ("pallas", 7)):
             curve = po.CURVES[name]
             pts = cref.gen_points(name, 600 + n, n)
             sc = cref.synth_scalars(601 + n, n, curve.scalar_bits)
             expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
+            assert expect == cref.msm_by_discrete_logs(name, 600 + n, sc)
             for chunks in ((0, 1, 2, 3, 4, 8) if n > 100000 else (0, 2, 3)):
                 assert L.ctt_hip_msm_set_option(None, b"chunks", chunks) == 0
                 assert _decode(curve, "jac", multiScalarMul_vartime(name, sc, pts, coord="jac")) == expect, (name, chunks)
