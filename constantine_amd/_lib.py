@@ -33,7 +33,7 @@ def exported_symbols():
              "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min", "ctt_hip_subgroup_check", "ctt_hip_fr_quotient",
              "ctt_hip_msm_host", "ctt_hip_msm_available",
              # part 3: the MSM's callers under the reference's names + their host-only pieces
-             "ctt_eth_kzg_context_new", "ctt_eth_kzg_context_delete", "ctt_eth_kzg_blob_to_kzg_commitment", "ctt_eth_kzg_compute_kzg_proof",
+             "ctt_eth_kzg_context_new", "ctt_eth_kzg_context_new_with_precompute", "ctt_eth_kzg_context_delete", "ctt_eth_kzg_blob_to_kzg_commitment", "ctt_eth_kzg_compute_kzg_proof",
              "ctt_eth_kzg_compute_blob_kzg_proof", "ctt_eth_kzg_blob_to_kzg_commitment_parallel", "ctt_eth_kzg_compute_kzg_proof_parallel",
              "ctt_eth_kzg_compute_blob_kzg_proof_parallel", "ctt_eth_evm_bls12381_g1msm", "ctt_eth_evm_bls12381_g2msm",
              "ctt_hip_eth_kzg_context_from_srs", "ctt_hip_sha256", "ctt_hip_bls12_381_g1_decompress", "ctt_hip_bls12_381_g1_compress",
@@ -106,6 +106,8 @@ def lib():
         u8 = ctypes.c_uint8   # the reference's status enums are __attribute__((__packed__)): one byte
         L.ctt_eth_kzg_context_new.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, u8]
         L.ctt_eth_kzg_context_new.restype = u8
+        L.ctt_eth_kzg_context_new_with_precompute.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, u8, i32, i32]
+        L.ctt_eth_kzg_context_new_with_precompute.restype = u8
         L.ctt_eth_kzg_context_delete.argtypes = [vp]
         L.ctt_eth_kzg_context_delete.restype = None
         L.ctt_eth_kzg_blob_to_kzg_commitment.argtypes = [vp, vp, vp]

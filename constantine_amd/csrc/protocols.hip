@@ -616,6 +616,12 @@ uint8_t ctt_eth_kzg_context_new(ctt_eth_kzg_context_struct** ctx, const char* fi
   // the SRS as a window table: 10 MB for 4096 points, commitments 0.38 instead of 0.52 ms (profiles/kzg_timing_r04.txt)
   return (uint8_t)kzg_context_build(ctx, srs.data(), dv ? atoi(dv) : 0, 1);
 }
+// ethereum_eip4844_kzg.h:232: the reference's constructor with PrecomputedMSM lookup tables (t base groups, b bits per window -- CPU
+// tables for the FK20 proofs of PeerDAS).  The same context as above: the SRS is cached on the GPU as a window table whatever t and b
+// say; the PeerDAS functions those tables serve are not part of this library.
+uint8_t ctt_eth_kzg_context_new_with_precompute(ctt_eth_kzg_context_struct** ctx, const char* filepath, uint8_t format, int /*t*/, int /*b*/) {
+  return ctt_eth_kzg_context_new(ctx, filepath, format);
+}
 void ctt_eth_kzg_context_delete(ctt_eth_kzg_context_struct* c) {
   if (!c) return;
   {

@@ -77,13 +77,17 @@ class EthereumKZGContext:
         self.handle = h
 
     @classmethod
-    def from_ckzg_text(cls, path):
+    def from_ckzg_text(cls, path, precompute=None):
         """ctt_eth_kzg_context_new(ctx, filepath, cttEthTSFormat_ckzg4844): the c-kzg text format of the Ethereum ceremony, as
-        shipped by the reference in constantine/commitments_setups/trusted_setup_ethereum_kzg4844_reference.dat."""
+        shipped by the reference in constantine/commitments_setups/trusted_setup_ethereum_kzg4844_reference.dat.
+        precompute = (t, b): through ctt_eth_kzg_context_new_with_precompute (the reference's table sizes; the same context here)."""
         self = cls.__new__(cls)
         self.L = _lib.lib()
         h = ctypes.c_void_p()
-        rc = self.L.ctt_eth_kzg_context_new(ctypes.byref(h), str(path).encode(), 0)
+        if precompute is not None:
+            rc = self.L.ctt_eth_kzg_context_new_with_precompute(ctypes.byref(h), str(path).encode(), 0, int(precompute[0]), int(precompute[1]))
+        else:
+            rc = self.L.ctt_eth_kzg_context_new(ctypes.byref(h), str(path).encode(), 0)
         if rc != 0:
             raise ValueError(cttEthTrustedSetupStatus(rc).name)
         self.handle = h

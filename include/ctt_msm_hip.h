@@ -298,6 +298,9 @@ typedef enum __attribute__((__packed__)) {
 /* the c-kzg text format of the Ethereum ceremony; the SRS is cached on $CTT_HIP_DEVICE (default 0) */
 ctt_eth_trusted_setup_status ctt_eth_kzg_context_new(ctt_eth_kzg_context** ctx, const char* filepath,
                                                      ctt_eth_trusted_setup_format format);
+/* ethereum_eip4844_kzg.h:232 -- t, b size the reference's CPU lookup tables (PeerDAS); accepted, the same context as above */
+ctt_eth_trusted_setup_status ctt_eth_kzg_context_new_with_precompute(ctt_eth_kzg_context** ctx, const char* filepath,
+                                                                     ctt_eth_trusted_setup_format format, int t, int b);
 void ctt_eth_kzg_context_delete(ctt_eth_kzg_context* ctx);
 ctt_eth_kzg_status ctt_eth_kzg_blob_to_kzg_commitment(const ctt_eth_kzg_context* ctx, ctt_eth_kzg_commitment* dst,
                                                       const ctt_eth_kzg_blob* blob);

@@ -223,6 +223,11 @@ def test_kzg_context_from_the_ceremony_text_file(tmp_path):
         assert kzg.blob_to_kzg_commitment(ctx, blob) == com
     finally:
         ctx.delete()
+    ctx = kzg.EthereumKZGContext.from_ckzg_text(path, precompute=(256, 8))     # ctt_eth_kzg_context_new_with_precompute
+    try:
+        assert kzg.blob_to_kzg_commitment(ctx, blob) == com
+    finally:
+        ctx.delete()
     with pytest.raises(ValueError, match="cttEthTS_MissingOrInaccessibleFile"):
         kzg.EthereumKZGContext.from_ckzg_text(tmp_path / "nope.txt")
     bad = tmp_path / "bad.txt"
