@@ -6,4 +6,8 @@
 #define CTT_FPU_CHAIN 14
 #endif  // CTT_FPU_CHAIN
 #include "hip_backend.h"
+#ifdef CTT_TU_ACCUM_INTO   // (the second build of this file, into_bls12_381_g1.o: the accumulate kernel's INTO form only -- hip_backend.h)
+template void ctt::launch_accum_into<ctt::Bls12381G1::FD>(hipStream_t, const ctt::AccumArgs<ctt::Bls12381G1::FD>&, uint32_t);
+#else
 extern "C" const ctt::CurveOps* ctt_ops_bls12_381_g1(void) { return ctt::CurveImpl<ctt::Bls12381G1>::ops(); }
+#endif

@@ -10,4 +10,8 @@
 #define CTT_ACCUM_WAVES 4
 #endif
 #include "hip_backend.h"
+#ifdef CTT_TU_ACCUM_INTO   // (the second build of this file, into_bn254_snarks_g1.o: the accumulate kernel's INTO form only -- hip_backend.h)
+template void ctt::launch_accum_into<ctt::Bn254G1::FD>(hipStream_t, const ctt::AccumArgs<ctt::Bn254G1::FD>&, uint32_t);
+#else
 extern "C" const ctt::CurveOps* ctt_ops_bn254_snarks_g1(void) { return ctt::CurveImpl<ctt::Bn254G1>::ops(); }
+#endif

@@ -10,4 +10,8 @@
 #define CTT_ACCUM_WAVES 4
 #endif
 #include "hip_backend.h"
+#ifdef CTT_TU_ACCUM_INTO   // (the second build of this file, into_pallas.o: the accumulate kernel's INTO form only -- hip_backend.h)
+template void ctt::launch_accum_into<ctt::PallasEc::FD>(hipStream_t, const ctt::AccumArgs<ctt::PallasEc::FD>&, uint32_t);
+#else
 extern "C" const ctt::CurveOps* ctt_ops_pallas(void) { return ctt::CurveImpl<ctt::PallasEc>::ops(); }
+#endif

@@ -404,6 +404,18 @@ __global__ void k_field_op(int op, const F* a, const F* b, F* r, uint32_t n) {
 // ---------------------------------------------------------------------------------------------
 // HIP backend
 // ---------------------------------------------------------------------------------------------
+// k_accum<F, true> lives in a translation unit of its own per curve (the curve's .hip compiled again with -DCTT_TU_ACCUM_INTO, Makefile
+// into_%.o): k_accum is by far the slowest kernel to compile (BLS12-381 G2: two minutes), and its second form then builds beside the
+// first one instead of after it.  Declared here, defined and explicitly instantiated there.
+template <class F>
+void launch_accum_into(hipStream_t stream, const AccumArgs<F>& a, uint32_t W);
+#ifdef CTT_TU_ACCUM_INTO
+template <class F>
+void launch_accum_into(hipStream_t stream, const AccumArgs<F>& a, uint32_t W) {
+  hipLaunchKernelGGL((k_accum<F, true>), dim3((a.G + ACCUM_BLOCK - 1) / ACCUM_BLOCK, W), dim3(ACCUM_BLOCK), 0, stream, a);
+}
+#endif
+
 struct HipBackend {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -606,7 +618,7 @@ struct HipBackend {
   // into: the bucket set holds earlier sums that the runs continue (a later slice of a host-pointer MSM, accum_body_xyzz)
   template <class F>
   void launch_accum(const AccumArgs<F>& a, uint32_t W, bool into = false) {
-    if (into) hipLaunchKernelGGL((k_accum<F, true>), grid2(a.G, ACCUM_BLOCK, W), dim3(ACCUM_BLOCK), 0, stream, a);
+    if (into) launch_accum_into<F>(stream, a, W);
     else hipLaunchKernelGGL((k_accum<F, false>), grid2(a.G, ACCUM_BLOCK, W), dim3(ACCUM_BLOCK), 0, stream, a);
     HIP_CHECK(hipGetLastError());
   }
