@@ -710,6 +710,10 @@ struct CurveOps {
   // the same check on the host, for a handful of host-resident points (a precompile call, one commitment): a single GPU lane
   // walks the 255 dependent doublings of [r]P in ~6.5 ms whatever n is, a CPU core needs ~0.2 ms per G1 point
   void (*subgroup_check_host)(const void* pts_aff, size_t first, size_t step, size_t n, uint8_t* ok);
+  // cached bases (records, or a window table when table_c > 0) with HOST-resident coefficients: the coefficients go up in slices
+  // underneath the accumulation like the pairs of submit_host (MsmEngine::submit_host with d_prepared)
+  int (*submit_host_bases)(void* eng, const MsmOptions* opt, const void* h_coefs, int coef_is_fr, const void* d_prepared, uint32_t n,
+                           int table_c, uint32_t table_n, void* d_stage_coefs, int chunks, int* plan);
 };
 
 template <class C>
@@ -745,6 +749,19 @@ struct CurveImpl {
     if (sl < 0) return sl;
     const MsmPlan& p = e.last_plan;
     plan[0] = p.c; plan[1] = p.W; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
+    plan[7] = (int)e.last_chunks;
+    return sl;
+  }
+  static int submit_host_bases(void* eng, const MsmOptions* opt, const void* h_coefs, int coef_is_fr, const void* d_prepared, uint32_t n,
+                               int table_c, uint32_t table_n, void* d_stage_coefs, int chunks, int* plan) {
+    Engine& e = *(Engine*)eng;
+    uint32_t lanes = e.opt.lanes;
+    e.opt = *opt;
+    e.opt.lanes = lanes;
+    int sl = e.submit_host(h_coefs, coef_is_fr != 0, nullptr, n, d_stage_coefs, nullptr, chunks, d_prepared, table_c, table_n);
+    if (sl < 0) return sl;
+    const MsmPlan& p = e.last_plan;
+    plan[0] = p.c; plan[1] = p.Wd; plan[2] = (int)p.K; plan[3] = (int)p.G; plan[4] = (int)p.S; plan[5] = (int)lanes;
     plan[7] = (int)e.last_chunks;
     return sl;
   }
@@ -869,7 +886,7 @@ struct CurveImpl {
     return 0;
   }
   static const CurveOps* ops() {
-    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F), subgroup_check, table_prepare, fr_quotient, sizeof(typename C::Fr), subgroup_check_host};
+    static const CurveOps o = {C::ID, sizeof(Affine<F>), create, destroy, submit, finish, submit_host, bases_prepare, submit_bases, gen_points, field_op, ec_sum_affine, sum_reduce, batch_affine, sizeof(F), subgroup_check, table_prepare, fr_quotient, sizeof(typename C::Fr), subgroup_check_host, submit_host_bases};
     return &o;
   }
 };

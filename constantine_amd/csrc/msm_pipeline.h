@@ -787,8 +787,9 @@ struct MsmEngine {
   // 2^22 14.0-14.2 / 13.3-13.8, 2^24 52.1 / 49.6-50.1; G2 2^20 12.8-13.0 / 12.1-12.2; BN254 2^22 9.33-9.35 / 8.64-8.75; Pallas 2^20 2.87 / 2.86.
   // Every slice a multiple of 64 pairs except the last.  An explicit slice count is honoured.
   static constexpr double HOST_SLICE_FIX_NS = 1.9e5;
-  static std::vector<uint32_t> host_slices(uint32_t n, int want) {
-    const double gpu_ns = (double)((C::BITS + 16) / 16) * C::ACC_NS * 1.09, copy_ns = (double)(32 + sizeof(Affine<F>)) / 56.0;
+  static std::vector<uint32_t> host_slices(uint32_t n, int want, bool scalars_only = false) {
+    // (scalars_only: the bases are cached on the device, 32 bytes per pair cross the link)
+    const double gpu_ns = (double)((C::BITS + 16) / 16) * C::ACC_NS * 1.09, copy_ns = (double)(32 + (scalars_only ? 0 : sizeof(Affine<F>))) / 56.0;
     auto sizes = [&](uint32_t nch, double r) {
       std::vector<uint32_t> bound(nch + 1, 0);
       double wsum = 0, w = 1;
@@ -840,11 +841,17 @@ struct MsmEngine {
     }
     return best;
   }
+  // d_prepared (with table_c / table_n for a window table): the bases are cached on the device (prepare_bases / prepare_table), only the
+  // coefficients are host-resident -- the ZAL msm_with_cached_base shape with host scalars; h_points and d_stage_points are not used.
   int submit_host(const void* h_coefs, bool coef_is_fr, const void* h_points, uint32_t n, void* d_stage_coefs,
-                  void* d_stage_points, int want_chunks) {
+                  void* d_stage_points, int want_chunks, const void* d_prepared = nullptr, int table_c = 0, uint32_t table_n = 0) {
     const int sl = claim_slot(n);
     if (sl < 0 || n == 0) return sl;
-    const std::vector<uint32_t> bound = host_slices(n, want_chunks);
+    const std::vector<uint32_t> bound = host_slices(n, want_chunks, d_prepared != nullptr);
+    const size_t prepared_stride = kConvert ? (size_t)gather_stride<FD>() : sizeof(Affine<F>);
+    auto plan_of = [&](uint32_t cnt, const MsmOptions& oo) {
+      return table_c > 0 ? make_table_plan(cnt, C::BITS, table_c, table_n, oo) : make_plan(cnt, C::BITS, oo);
+    };
     const uint32_t nch = (uint32_t)bound.size() - 1;
     uint32_t largest = 0;
     for (uint32_t i = 0; i < nch; i++) largest = bound[i + 1] - bound[i] > largest ? bound[i + 1] - bound[i] : largest;
@@ -854,13 +861,15 @@ struct MsmEngine {
     if (o.c <= 0) o.c = choose_window_bits(n, C::BITS, o.lanes, o.acc_ns, o.red_ns);  // one window size for the whole MSM
     try {
     bk.stage_begin(sl, ST_TOTAL);
-    const MsmPlan p0 = make_plan(largest, C::BITS, o);   // the largest slice sizes the workspace
+    const MsmPlan p0 = plan_of(largest, o);   // the largest slice sizes the workspace
     // ONE bucket set for all slices (round 4): the accumulation of slice i > 0 continues the stored sums (k_accum<FD, true>).  Rounds
     // 2-3 gave every slice its own set and added the sets afterwards: a full addition per bucket and slice, 0.24 ms of a 4.6 ms call
     // at 2^20 BLS12-381 G1 in three slices (k_bucket_sum, profiles/hostptr_timeline_r04.txt).
     XYZZ<FD>* d_sets = (XYZZ<FD>*)need(bucketsS[sl], (size_t)p0.W * p0.B * sizeof(XYZZ<FD>));
     void* d_conv_all = nullptr;
-    if constexpr (kConvert) d_conv_all = need(cpoints, (size_t)n * gather_stride<FD>());
+    if constexpr (kConvert) {
+      if (!d_prepared) d_conv_all = need(cpoints, (size_t)n * gather_stride<FD>());
+    }
     reserve_stage1(sl, p0, coef_is_fr);
     MsmPlan plast = p0;
     Staged st_prev{};
@@ -868,7 +877,8 @@ struct MsmEngine {
     auto upload = [&](uint32_t i) {
       const uint32_t start = bound[i], cnt = bound[i + 1] - bound[i];
       bk.h2d((uint32_t*)d_stage_coefs + (size_t)start * 8, (const char*)h_coefs + (size_t)start * 32, (size_t)cnt * 32);
-      bk.h2d((Affine<F>*)d_stage_points + start, (const char*)h_points + (size_t)start * sizeof(Affine<F>), (size_t)cnt * sizeof(Affine<F>));
+      if (!d_prepared)
+        bk.h2d((Affine<F>*)d_stage_points + start, (const char*)h_points + (size_t)start * sizeof(Affine<F>), (size_t)cnt * sizeof(Affine<F>));
     };
     // Several slices: a thread of its own issues the copies back to back (HipBackend::h2d_slice_done has the reason), this one
     // enqueues slice i's kernels as soon as slice i has been handed to the link.
@@ -912,13 +922,15 @@ struct MsmEngine {
         merge_buckets(sl, p_prev, st_prev);
         bk.stage_chunk((int)i);
       }
-      const MsmPlan p = make_plan(cnt, C::BITS, o);
+      const MsmPlan p = plan_of(cnt, o);
       if (p.W != p0.W || p.B != p0.B) {   // (the slices share one bucket set: same windows, same buckets -- o.c is fixed above)
         fprintf(stderr, "[ctt_msm] FATAL: slice %u of a host-pointer MSM planned %u windows of %u buckets, the call %u of %u\n", i, p.W, p.B, p0.W, p0.B);
         abort();
       }
-      void* d_conv = kConvert ? (void*)((char*)d_conv_all + (size_t)start * gather_stride<FD>()) : nullptr;
-      st_prev = accumulate_pairs(sl, p, d_c, coef_is_fr, d_p, nullptr, d_conv, d_sets, /*into=*/i > 0);
+      void* d_conv = (kConvert && !d_prepared) ? (void*)((char*)d_conv_all + (size_t)start * gather_stride<FD>()) : nullptr;
+      // (cached bases: the slice's records -- or, in a window table, its column of every row block: row w * table_n + j -- start `start` records in)
+      const void* d_prep = d_prepared ? (const void*)((const char*)d_prepared + (size_t)start * prepared_stride) : nullptr;
+      st_prev = accumulate_pairs(sl, p, d_c, coef_is_fr, d_prepared ? nullptr : d_p, d_prep, d_conv, d_sets, /*into=*/i > 0);
       p_prev = p;
       plast = p;
     }

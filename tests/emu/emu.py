@@ -31,7 +31,7 @@ def lib():
         L.emu_field_op_dev.argtypes = [i32, i32, vp, vp, vp]
         L.emu_dev_field_info.argtypes = [i32, vp, vp]
         L.emu_msm_host.argtypes = [i32, i32, i32, vp, vp, vp, sz, i32, i32]
-        L.emu_msm_table.argtypes = [i32, i32, i32, vp, vp, vp, sz, sz, i32, i32]
+        L.emu_msm_table.argtypes = [i32, i32, i32, vp, vp, vp, sz, sz, i32, i32, i32]
         L.emu_sum_reduce.argtypes = [i32, i32, vp, vp, sz, i32]
         L.emu_batch_affine.argtypes = [i32, i32, vp, vp, sz, i32]
         L.emu_msm_slots.argtypes = [i32, vp, vp, vp, sz]
@@ -93,15 +93,16 @@ def msm_host(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, chunks=0):
     return out, used
 
 
-def msm_table(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, K=0):
+def msm_table(curve, coefs, points, coef_is_fr=False, out_kind=0, c=0, K=0, chunks=0):
     """Cached bases with a window table over all of `points` (MsmEngine::prepare_table); the MSM uses the first len(coefs).
+    chunks > 0: host-resident coefficients uploaded in that many slices (MsmEngine::submit_host with cached bases).
     Returns (result, window bits of the table)."""
     coefs = np.ascontiguousarray(coefs, dtype=np.uint8)
     points = np.ascontiguousarray(points, dtype=np.uint8)
     nco = 2 if out_kind == 0 else 3
     out = np.zeros(AFF_BYTES[curve] // 2 * nco, dtype=np.uint8)
     cu = lib().emu_msm_table(CURVE_ID[curve], int(coef_is_fr), out_kind, _p(out), _p(coefs), _p(points), points.shape[0],
-                             coefs.shape[0], c, K)
+                             coefs.shape[0], c, K, chunks)
     assert cu >= 0
     return out, cu
 

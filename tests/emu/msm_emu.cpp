@@ -164,8 +164,9 @@ struct EmuOps {
   // host-pointer form: the inputs are uploaded in `chunks` slices, one bucket set per slice (MsmEngine::submit_host)
   int (*msm_host)(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t n, int c, int chunks);
   // cached bases with a window table over `ntab` points (MsmEngine::prepare_table), MSM over the first n; returns the c used
+  // (chunks > 0: the coefficients are host-resident and go up in that many slices -- MsmEngine::submit_host with cached bases)
   int (*msm_table)(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t ntab, size_t n, int c,
-                   int K);
+                   int K, int chunks);
   void (*gen)(uint64_t seed, uint64_t first, uint32_t n, void* out);
   void (*fop)(int op, const void* a, const void* b, void* r);
   int (*fop_dev)(int op, const void* a, const void* b, void* r);
@@ -234,16 +235,18 @@ struct EmuCurve {
     return (int)eng.last_chunks;
   }
   static int msm_table(int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t ntab, size_t n,
-                       int c, int K) {
+                       int c, int K, int chunks) {
     EmuBackend bk;
     MsmEngine<C, EmuBackend> eng(bk);
     eng.opt.K = K;
     eng.opt.lanes = 4096;
     emu_env_options(eng.opt);
     int cu = 0;
-    void* tab = eng.prepare_table((const Affine<F>*)points, (uint32_t)ntab, c, &cu);
+    void* tab = c < 0 ? nullptr : eng.prepare_table((const Affine<F>*)points, (uint32_t)ntab, c, &cu);   // (c < 0: plain cached records)
     if (!tab && ntab) tab = eng.prepare_bases((const Affine<F>*)points, (uint32_t)ntab);   // (what bases_create does: plain records)
-    int s0 = eng.submit((const uint32_t*)coefs, coef_is_fr != 0, nullptr, (uint32_t)n, tab, cu, (uint32_t)ntab);
+    std::vector<unsigned char> sc(n * 32 + 64);
+    int s0 = chunks > 0 ? eng.submit_host(coefs, coef_is_fr != 0, nullptr, (uint32_t)n, sc.data(), nullptr, chunks, tab, cu, (uint32_t)ntab)
+                        : eng.submit((const uint32_t*)coefs, coef_is_fr != 0, nullptr, (uint32_t)n, tab, cu, (uint32_t)ntab);
     auto res = eng.finish(s0);
     if (tab) bk.free(tab);
     write_result<typename MsmEngine<C, EmuBackend>::HF>(r, res, out_kind);
@@ -405,9 +408,9 @@ int emu_plan(uint32_t n, int bits, uint32_t lanes, int table_c, uint32_t ntab, u
 }
 int emu_table_window_bits(uint32_t ntab, int bits) { return choose_table_window_bits(ntab, bits); }
 int emu_msm_table(int curve, int coef_is_fr, int out_kind, void* r, const void* coefs, const void* points, size_t ntab, size_t n,
-                  int c, int K) {
+                  int c, int K, int chunks) {
   const EmuOps* o = ops_of(curve);
-  return o ? o->msm_table(coef_is_fr, out_kind, r, coefs, points, ntab, n, c, K) : -1;
+  return o ? o->msm_table(coef_is_fr, out_kind, r, coefs, points, ntab, n, c, K, chunks) : -1;
 }
 int emu_gen_points(int curve, uint64_t seed, uint64_t first, uint32_t n, void* out) {
   const EmuOps* o = ops_of(curve);

@@ -296,10 +296,18 @@ def test_window_table_for_cached_bases(name):
         assert cu == c or c == 0
         assert cu > 0
         assert bytes(out) == bytes(expect), (name, c, cu)
+    # host-resident coefficients over the cached bases, uploaded in slices (MsmEngine::submit_host with d_prepared; round 4): a slice
+    # addresses its column of every row block of the table (row w * ntab + j), and its records when the bases are plain (c = -1)
+    for c, chunks in ((0, 1), (5, 2), (6, 3), (-1, 1), (-1, 3)):
+        out, cu = emu.msm_table(name, sc, pts, c=c, K=4, chunks=chunks)
+        assert bytes(out) == bytes(expect), (name, c, chunks)
+        assert (cu == 0) == (c < 0)
     # a prefix of the cached bases (table rows stay ntab apart)
     m = n // 3
     expect, _ = cref.msm(name, sc[:m], pts[:m])
     out, _ = emu.msm_table(name, sc[:m], pts, c=6, K=4)
+    assert bytes(out) == bytes(expect)
+    out, _ = emu.msm_table(name, sc[:m], pts, c=6, K=4, chunks=2)
     assert bytes(out) == bytes(expect)
     if curve.F.degree == 1:
         mont = cref.synth_scalars(803, n, 250)

@@ -78,6 +78,7 @@ timeout 300 python tools/bench_batch_ops.py > "$OUT/batch_ops_$TAG.txt" 2>> "$OU
 timeout 300 python bench.py --cpu-only --log2n 10 > "$OUT/bench_${TAG}_cpu_only_2pow10.json" 2>> "$OUT/bench.err"     # BASELINE configs[0]
 timeout 300 python tools/bench_kzg.py > "$OUT/kzg_timing_$TAG.txt" 2>> "$OUT/bench.err"
 timeout 300 python tools/bench_evm.py > "$OUT/evm_timing_$TAG.txt" 2>> "$OUT/bench.err"
+timeout 400 python tools/bench_cached_host_scalars.py > "$OUT/cached_host_scalars_$TAG.txt" 2>> "$OUT/bench.err"
 timeout 400 python tools/bench_crossover.py > "$OUT/crossover_$TAG.jsonl" 2>> "$OUT/bench.err"
 for k in 6 8 12 14; do timeout 300 python bench.py --cpu-only --log2n $k >> "$OUT/crossover_cpu_port_$TAG.jsonl" 2>> "$OUT/bench.err"; done   # the CPU port's side
 timeout 300 python tools/bench_contexts.py > "$OUT/hostptr_contexts_one_gpu_$TAG.txt" 2>> "$OUT/bench.err"
