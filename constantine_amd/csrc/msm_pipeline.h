@@ -790,6 +790,7 @@ struct MsmEngine {
   static std::vector<uint32_t> host_slices(uint32_t n, int want, bool scalars_only = false) {
     // (scalars_only: the bases are cached on the device, 32 bytes per pair cross the link)
     const double gpu_ns = (double)((C::BITS + 16) / 16) * C::ACC_NS * 1.09, copy_ns = (double)(32 + (scalars_only ? 0 : sizeof(Affine<F>))) / 56.0;
+    if (want <= 0 && n < (1u << 15)) return std::vector<uint32_t>{0u, n};   // (small calls stay whole; no search for a 4096-point commitment)
     auto sizes = [&](uint32_t nch, double r) {
       std::vector<uint32_t> bound(nch + 1, 0);
       double wsum = 0, w = 1;

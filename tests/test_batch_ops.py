@@ -148,6 +148,13 @@ def test_gpu_device_resident_primitives_at_scale():
         eng.batch_affine(name, d_out, d_src, m, src_coord=kind)
         torch.cuda.synchronize()
         assert bytes(d_out.cpu().numpy()) == bytes(expect), kind
+        # the Constantine symbol on HOST arrays large enough for its slices (4 from 2^19 points, 8 from 2^21: uploads on a helper thread,
+        # kernel and download per slice -- ctt_hip_batch_affine): the same rows repeated, ragged lengths
+        from constantine_amd import batchAffine_vartime
+        for big in ((1 << 19) + 333, (1 << 21) + 5) if kind == "jac" else ((1 << 19) + 64,):
+            reps = big // m + 1
+            got = batchAffine_vartime(name, np.tile(src, (reps, 1))[:big], coord=kind)
+            assert bytes(got) == bytes(np.tile(expect, (reps, 1))[:big]), (kind, big)
     # Jacobian with Z = 1 (Montgomery one) must come back unchanged; Z = 0 rows become the neutral
     one = np.frombuffer(po.CURVES[name].F.to_mont_bytes(1), dtype=np.uint8)
     d_jac = torch.empty((n, 3 * info.coord_bytes), dtype=torch.uint8, device="cuda")
