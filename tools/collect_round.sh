@@ -75,6 +75,7 @@ for k in 16 17 18 19 22 24; do
   timeout 300 python bench.py --log2n $k --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g1_2pow$k.json" 2>> "$OUT/bench.err"
 done
 timeout 300 python tools/bench_batch_ops.py > "$OUT/batch_ops_$TAG.txt" 2>> "$OUT/bench.err"
+timeout 300 python tools/bench_batch_ops_host.py > "$OUT/batch_affine_host_collection_$TAG.txt" 2>> "$OUT/bench.err"
 timeout 300 python bench.py --cpu-only --log2n 10 > "$OUT/bench_${TAG}_cpu_only_2pow10.json" 2>> "$OUT/bench.err"     # BASELINE configs[0]
 timeout 300 python tools/bench_kzg.py > "$OUT/kzg_timing_$TAG.txt" 2>> "$OUT/bench.err"
 timeout 300 python tools/bench_evm.py > "$OUT/evm_timing_$TAG.txt" 2>> "$OUT/bench.err"
