@@ -959,12 +959,17 @@ def test_concurrent_callers_are_serialised():
     import threading
     from constantine_amd import multiScalarMul_vartime_parallel
     jobs = []
+    # (the two large ones go up in three or more slices: a helper thread copies while the caller's thread enqueues -- round 4)
     for i, (name, n) in enumerate([("bls12_381_g1", 3000), ("bn254_snarks_g1", 5000), ("pallas", 700),
-                                   ("bls12_381_g1", 64), ("vesta", 2048), ("bn254_snarks_g1", 1)]):
+                                   ("bls12_381_g1", 64), ("vesta", 2048), ("bn254_snarks_g1", 1),
+                                   ("bls12_381_g1", (1 << 19) + 9), ("pallas", (1 << 20) + 1)]):
         curve = po.CURVES[name]
         pts = cref.gen_points(name, 1300 + i, n)
         sc = cref.synth_scalars(1400 + i, n, curve.scalar_bits)
-        jobs.append((name, curve, sc, pts, _aff(curve, cref.msm(name, sc, pts, nthreads=4)[0])))
+        expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT if n > 100000 else 4)[0])
+        if n > 100000:
+            assert expect == cref.msm_by_discrete_logs(name, 1300 + i, sc)
+        jobs.append((name, curve, sc, pts, expect))
     results = [None] * len(jobs)
 
     def work(k):
