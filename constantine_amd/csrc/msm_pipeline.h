@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <functional>
 #include <system_error>
 #include <thread>
 #include <type_traits>
@@ -495,8 +496,12 @@ struct MsmEngine {
     need(hkey, W * p.G * 4);
     need(tkey, W * p.G * 4);
   }
+  // points_arrive (submit_host, a slice copied by the submitting thread): the points of this slice are not on the device yet -- the
+  // digits and the sort need the coefficients only, so they are enqueued first, the hook then copies the points (the thread sits in that
+  // copy while the GPU sorts) and the conversion follows the sort instead of preceding it.
   Staged accumulate_pairs(int sl, const MsmPlan& p, const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in,
-                          const void* d_prepared, void* d_converted, XYZZ<FD>* d_buckets, bool into = false) {
+                          const void* d_prepared, void* d_converted, XYZZ<FD>* d_buckets, bool into = false,
+                          const std::function<void()>* points_arrive = nullptr) {
     const uint32_t n = p.n, W = p.W, B = p.B;
     bk.stage_begin(sl, ST_DIGITS);
     const uint32_t* d_scalars = d_coefs;
@@ -507,11 +512,12 @@ struct MsmEngine {
     }
     const void* d_points;
     uint32_t point_stride;
+    const bool convert_late = points_arrive != nullptr;
     if constexpr (kConvert) {
       if (d_prepared) {
         d_points = d_prepared;
       } else {
-        bk.template launch_convert<F, FD>(d_points_in, d_converted, n);
+        if (!convert_late) bk.template launch_convert<F, FD>(d_points_in, d_converted, n);
         d_points = d_converted;
       }
       point_stride = gather_stride<FD>();
@@ -543,6 +549,12 @@ struct MsmEngine {
     bk.memset0(st.d_maxcount, 8);
     sa.bstart = st.d_bstart; sa.entries = d_entries; sa.maxcount = st.d_maxcount;
     bk.launch_digits_sort(sa);   // (leaves the largest bucket in d_maxcount[0]: the merge kernels read it there)
+    if (convert_late) {
+      (*points_arrive)();
+      if constexpr (kConvert) {
+        if (!d_prepared) bk.template launch_convert<F, FD>(d_points_in, d_converted, n);   // (timed with the sort in this form)
+      }
+    }
     bk.stage_end(sl, ST_SORT);
 
     // The previous MSM's tail (narrow reduction passes + result copy on the backend's second stream) has had this MSM's
@@ -875,11 +887,18 @@ struct MsmEngine {
     MsmPlan plast = p0;
     Staged st_prev{};
     MsmPlan p_prev = p0;
-    auto upload = [&](uint32_t i) {
+    auto upload_coefs = [&](uint32_t i) {
       const uint32_t start = bound[i], cnt = bound[i + 1] - bound[i];
       bk.h2d((uint32_t*)d_stage_coefs + (size_t)start * 8, (const char*)h_coefs + (size_t)start * 32, (size_t)cnt * 32);
+    };
+    auto upload_points = [&](uint32_t i) {
+      const uint32_t start = bound[i], cnt = bound[i + 1] - bound[i];
       if (!d_prepared)
         bk.h2d((Affine<F>*)d_stage_points + start, (const char*)h_points + (size_t)start * sizeof(Affine<F>), (size_t)cnt * sizeof(Affine<F>));
+    };
+    auto upload = [&](uint32_t i) {
+      upload_coefs(i);
+      upload_points(i);
     };
     // Several slices: a thread of its own issues the copies back to back (HipBackend::h2d_slice_done has the reason), this one
     // enqueues slice i's kernels as soon as slice i has been handed to the link.
@@ -915,9 +934,18 @@ struct MsmEngine {
         }
         bk.h2d_slice_wait(i);                                                                     // main stream waits for the copies
       } else {
-        upload(i);
+        // this thread copies: the coefficients now, the points from inside accumulate_pairs, behind the launches of the sort -- which
+        // then runs while the points cross the link (round 4; 2^16 pairs: one slice, 2 MB of coefficients, 6 MB of points)
+        upload_coefs(i);
         bk.h2d_done();
       }
+      const std::function<void()> points_arrive = [&, i]() {
+        upload_points(i);
+        bk.h2d_done();
+      };
+      static const bool late_env = !(getenv("CTT_HIP_MSM_LATE_POINTS") && atoi(getenv("CTT_HIP_MSM_LATE_POINTS")) == 0);   // (0: both copies first)
+      const bool late_points = late_env && !threaded && !d_prepared;
+      if (!late_points && !threaded && !d_prepared) points_arrive();
       if (i > 0) {   // slice i-1's merge goes in front of slice i's kernels (shared workspace)
         bk.stage_chunk((int)i - 1);
         merge_buckets(sl, p_prev, st_prev);
@@ -931,7 +959,8 @@ struct MsmEngine {
       void* d_conv = (kConvert && !d_prepared) ? (void*)((char*)d_conv_all + (size_t)start * gather_stride<FD>()) : nullptr;
       // (cached bases: the slice's records -- or, in a window table, its column of every row block: row w * table_n + j -- start `start` records in)
       const void* d_prep = d_prepared ? (const void*)((const char*)d_prepared + (size_t)start * prepared_stride) : nullptr;
-      st_prev = accumulate_pairs(sl, p, d_c, coef_is_fr, d_prepared ? nullptr : d_p, d_prep, d_conv, d_sets, /*into=*/i > 0);
+      st_prev = accumulate_pairs(sl, p, d_c, coef_is_fr, d_prepared ? nullptr : d_p, d_prep, d_conv, d_sets, /*into=*/i > 0,
+                                 late_points ? &points_arrive : nullptr);
       p_prev = p;
       plast = p;
     }
