@@ -532,6 +532,10 @@ struct HipBackend {
   }
   void h2d_slice_done(uint32_t i) { HIP_CHECK(hipEventRecord(ev_slice[i], cpy)); }
   void h2d_slice_wait(uint32_t i) { HIP_CHECK(hipStreamWaitEvent(stream, ev_slice[i], 0)); }
+  // (the coefficients of slice i alone: the digits and the sort can start on them while the slice's points are still crossing)
+  hipEvent_t ev_coefs[MAX_CHUNKS] = {};
+  void h2d_coefs_done(uint32_t i) { HIP_CHECK(hipEventRecord(ev_coefs[i], cpy)); }
+  void h2d_coefs_wait(uint32_t i) { HIP_CHECK(hipStreamWaitEvent(stream, ev_coefs[i], 0)); }
   void d2h_async(int slot, void* dst_pinned, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst_pinned, src, b, hipMemcpyDeviceToHost, cur()));
     HIP_CHECK(hipEventRecord(ev_done[slot], cur()));

@@ -896,14 +896,10 @@ struct MsmEngine {
       if (!d_prepared)
         bk.h2d((Affine<F>*)d_stage_points + start, (const char*)h_points + (size_t)start * sizeof(Affine<F>), (size_t)cnt * sizeof(Affine<F>));
     };
-    auto upload = [&](uint32_t i) {
-      upload_coefs(i);
-      upload_points(i);
-    };
     // Several slices: a thread of its own issues the copies back to back (HipBackend::h2d_slice_done has the reason), this one
     // enqueues slice i's kernels as soon as slice i has been handed to the link.
     bool threaded = BK::THREADED_UPLOAD && nch > 2;   // (two slices: one gap of ~0.1 ms against a thread start of about as much -- measured: 2^18 1.85 ms without, 1.93 with)
-    std::atomic<uint32_t> uploaded{0};
+    std::atomic<uint32_t> uploaded{0}, coefs_up{0};
     std::thread uploader;
     struct Joiner {
       std::thread& t;
@@ -914,7 +910,15 @@ struct MsmEngine {
         uploader = std::thread([&]() {
           bk.uploader_begin();
           for (uint32_t i = 0; i < nch; i++) {
-            upload(i);
+            upload_coefs(i);
+            // An event between the two copies only for the first slice.  Measured with a record after every slice's coefficients
+            // (rocprofv3 --memory-copy-trace): the copy behind such a record started only when the accumulation running on the main
+            // stream had ended -- no overlap left, 2^20 pairs 5.5 ms instead of 4.4, 2^22 19.6 instead of 13.5.  (A record is a
+            // barrier packet in a hardware queue, and the copy ordered behind it waits for it; giving the copy stream a priority
+            // class of its own changed nothing.)  Behind the first slice's coefficients nothing long is running.
+            if (i == 0 && !d_prepared) bk.h2d_coefs_done(i);
+            coefs_up.store(i + 1, std::memory_order_release);
+            upload_points(i);
             bk.h2d_slice_done(i);
             uploaded.store(i + 1, std::memory_order_release);
           }
@@ -928,24 +932,42 @@ struct MsmEngine {
       bk.stage_chunk((int)i);   // stage events of this slice (the stage times of the call are the sums over its slices)
       uint32_t* d_c = (uint32_t*)d_stage_coefs + (size_t)start * 8;
       Affine<F>* d_p = (Affine<F>*)d_stage_points + start;
-      if (threaded) {
-        for (uint32_t spin = 0; uploaded.load(std::memory_order_acquire) <= i; spin++) {
+      auto await = [](std::atomic<uint32_t>& flag, uint32_t i) {
+        for (uint32_t spin = 0; flag.load(std::memory_order_acquire) <= i; spin++) {
           if (spin < 20000u) cpu_relax(); else std::this_thread::yield();
         }
-        bk.h2d_slice_wait(i);                                                                     // main stream waits for the copies
+      };
+      // The first slice starts on its coefficients: the digits and the sort need nothing else, and they run while the slice's points
+      // cross the link (accumulate_pairs, points_arrive).  Later slices wait for both copies at once (their sort queues behind the
+      // previous accumulation anyway, and an event between their copies would hold the second one back: see the uploader).
+      static const bool late_env = !(getenv("CTT_HIP_MSM_LATE_POINTS") && atoi(getenv("CTT_HIP_MSM_LATE_POINTS")) == 0);   // (0: both copies first)
+      const bool late_points = late_env && i == 0 && !d_prepared;
+      if (threaded) {
+        if (late_points) {
+          await(coefs_up, i);
+          bk.h2d_coefs_wait(i);                                                                   // main stream waits for the coefficients
+        } else {
+          await(uploaded, i);
+          bk.h2d_slice_wait(i);                                                                   // ... for both copies
+        }
       } else {
-        // this thread copies: the coefficients now, the points from inside accumulate_pairs, behind the launches of the sort -- which
-        // then runs while the points cross the link (round 4; 2^16 pairs: one slice, 2 MB of coefficients, 6 MB of points)
         upload_coefs(i);
-        bk.h2d_done();
+        if (late_points) bk.h2d_done();
+        else {
+          upload_points(i);
+          bk.h2d_done();
+        }
       }
       const std::function<void()> points_arrive = [&, i]() {
-        upload_points(i);
-        bk.h2d_done();
+        if (threaded) {
+          await(uploaded, i);     // (the uploader thread has handed the slice's points to the link)
+          bk.h2d_slice_wait(i);
+        } else {
+          upload_points(i);
+          bk.h2d_done();
+        }
       };
-      static const bool late_env = !(getenv("CTT_HIP_MSM_LATE_POINTS") && atoi(getenv("CTT_HIP_MSM_LATE_POINTS")) == 0);   // (0: both copies first)
-      const bool late_points = late_env && !threaded && !d_prepared;
-      if (!late_points && !threaded && !d_prepared) points_arrive();
+
       if (i > 0) {   // slice i-1's merge goes in front of slice i's kernels (shared workspace)
         bk.stage_chunk((int)i - 1);
         merge_buckets(sl, p_prev, st_prev);

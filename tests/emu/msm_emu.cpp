@@ -40,6 +40,8 @@ struct EmuBackend {
   void uploader_begin() {}
   void h2d_slice_done(uint32_t) {}
   void h2d_slice_wait(uint32_t) {}
+  void h2d_coefs_done(uint32_t) {}
+  void h2d_coefs_wait(uint32_t) {}
   void launch_iota(uint32_t* entries, uint32_t n, uint32_t* bstart, uint32_t* maxcount) {
     for (uint32_t j = 0; j < (n ? n : 1); j++) iota_body(entries, n, bstart, maxcount, j);
   }

@@ -19,8 +19,12 @@ for t in mc:
         break
 rows.sort()
 # last MSM: from the last big gap (> 3 ms idle) onward
-starts = [i for i in range(1, len(rows)) if rows[i][0] - max(r[1] for r in rows[max(0,i-5):i]) > 300_000]
-first = starts[-1] if starts else 0
+if len(sys.argv) > 2:      # python tools/timeline_copies.py <db> <ms>: everything in the last <ms> milliseconds
+    t_end = max(r[1] for r in rows)
+    first = next(i for i, r in enumerate(rows) if r[0] >= t_end - float(sys.argv[2]) * 1e6)
+else:
+    starts = [i for i in range(1, len(rows)) if rows[i][0] - max(r[1] for r in rows[max(0,i-5):i]) > 300_000]
+    first = starts[-1] if starts else 0
 t0 = rows[first][0]
 for s, e, nm in rows[first:]:
     if "k_pyr" in nm: continue
