@@ -10,10 +10,12 @@ bench.py -- MSM throughput on MI355X (BASELINE.json metric: MSM points/sec, BLS1
 
 A "step" is one complete MSM (digits -> sort -> bucket accumulation -> bucket reduction -> window combine ->
 affine result on the host) over synthetic inputs that are ALREADY RESIDENT IN HBM when the timed region starts.
-With N GPUs every rank owns 2^log2n pairs (weak scaling: the job is one MSM over N * 2^log2n pairs, sharded by points
-exactly like the reference's msm-level split, ec_multi_scalar_mul_parallel.nim:386-431); each step ends with an
-all_gather of one affine point per rank over RCCL and the host-side sum of the partials.  --total-log2n fixes the
-whole job instead (strong scaling, 2^total / N pairs per rank).
+With N GPUs the job is ONE MSM sharded by points exactly like the reference's msm-level split
+(ec_multi_scalar_mul_parallel.nim:386-431); each step ends with an all_gather of one affine point per rank over RCCL and the
+host-side sum of the partials.  `--gpus N` with no size flag is the BASELINE metric: 2^20 pairs IN TOTAL (strong scaling,
+2^20 / N pairs per rank) as `value`, with the weak form (2^20 pairs per GPU) and, at N = 8, BASELINE configs[3] (2^24 pairs in
+total) timed in the same run and reported as extra keys of the same line.  --total-log2n T times 2^T pairs in total only,
+--log2n L (with N > 1) 2^L pairs per GPU only (weak scaling).
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).  Beside the pipelined `value` the line
 carries, at N = 1, `latency_ms_blocking` (median wall time of single blocking device-resident calls -- the reference
@@ -126,7 +128,8 @@ def cpu_only_leg(args):
                          "serial_value": n / statistics.median(runs1),
                          "sample": f"all 2^{args.log2n} pairs, median of 5 runs of {iters} calls, {cores} threads on a {budget}-CPU quota "
                                    f"({cpu_model()}); {flags}; oracle/msm_ref.cpp is a restatement of Constantine's algorithm, not "
-                                   "Constantine (no endomorphism, no assembly)"},
+                                   "Constantine (its endomorphism pre-split where the reference applies it -- here it does; 64-bit C++ "
+                                   "Montgomery arithmetic instead of its assembly)"},
         "parity_port_vs_bigint_oracle": bool(info.aff_from_bytes(bytes(got_m)) == expect),
         "parity_threads_vs_serial": bool(bytes(exp) == bytes(exp1)),
         "reference_toolchain": tool,
@@ -135,6 +138,19 @@ def cpu_only_leg(args):
     if tool["can_run_reference"]:
         out["reference_bench_output"] = run_reference_bench(tool["reference_checkout"], curve)
     print(json.dumps(out), flush=True)
+
+
+def kernel_sources_digest():
+    """sha256 over the HIP sources of the library (constantine_amd/csrc/*.h, *.hip), in name order: what a counter file in
+    profiles/ was measured on (tools/pmc_summary.py records the same digest; the GPU box has no .git to ask)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "constantine_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def host_cpu_budget():
@@ -188,7 +204,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--curve", default="bls12_381_g1")
-    ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU = 2^log2n (weak scaling)")
+    ap.add_argument("--log2n", type=int, default=None, help="pairs per GPU = 2^log2n (default 20; with --gpus N > 1 it selects "
+                    "weak scaling -- without it the N-GPU line is the strong form, 2^20 pairs in total)")
     ap.add_argument("--total-log2n", type=int, default=0, help="total pairs = 2^this, split over the GPUs (strong scaling; "
                     "BASELINE configs[3] is --gpus 8 --total-log2n 24)")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="pairs timed on the CPU baseline")
@@ -200,6 +217,9 @@ def main():
     ap.add_argument("--cpu-only", action="store_true", help="BASELINE.json configs[0]: the CPU port against the big-integer oracle, "
                     "no GPU (use with --log2n 10)")
     args = ap.parse_args()
+    explicit_log2n = args.log2n is not None
+    if args.log2n is None:
+        args.log2n = 20
 
     if args.cpu_only:
         return cpu_only_leg(args)
@@ -232,41 +252,17 @@ def main():
 
     curve = args.curve
     info = CURVES[curve]
-    strong = args.total_log2n > 0
-    if strong:
-        total = 1 << args.total_log2n
-        first, n = parallel.shard_bounds(total, world, rank)     # balanced contiguous slices (partitioners.nim:44-77)
-    else:
-        n = 1 << args.log2n
-        total = world * n
-        first = rank * n
+    # which job is `value`?  N = 1: 2^log2n pairs.  N > 1: --total-log2n T -> 2^T pairs in total (strong); --log2n L -> 2^L pairs per
+    # GPU (weak); neither -> the BASELINE metric, 2^20 pairs in total (strong), with the weak form and configs[3] as extra legs
+    strong = args.total_log2n > 0 or (world > 1 and not explicit_log2n)
+    driver_form = world > 1 and not explicit_log2n and args.total_log2n <= 0
+    main_total_log2 = args.total_log2n if args.total_log2n > 0 else 20
     seed = 0x5EED0000 + 2  # fixed seed = 0x5EED_0000 + config index
     eng = DeviceMsm(local_rank)
     # the roofline needs the accumulate kernel's time over the timed region: mode 2 records that stage (and the total) only --
     # every event record is a barrier packet in the queue, and all twelve cost a small pipelined MSM 15 % (2^16: 0.63 ms per
     # step against 0.55); the full stage breakdown comes from one blocking call after the timed region (stage_ms_blocking)
     eng.enable_timings(2)
-    # ... and below 2^20 pairs only every fourth MSM carries them (four records cost a 0.5 ms step 12 %: 2^16 0.53 ms per step
-    # against 0.47 without); the kernel's average duration is then over those launches of the timed region
-    ev_every = 1 if n >= (1 << 20) else 4
-    eng.set_option("timings_every", ev_every)
-
-    # ---- synthetic inputs, resident in HBM -----------------------------------------------------------
-    d_points = torch.empty((n, info.aff_bytes), dtype=torch.uint8, device="cuda")
-    eng.gen_points(curve, seed, n, d_points, first=first)            # P_i = [s_i]G, uniform over the subgroup
-    scal = synth_scalars(seed + 1, n, info.scalar_bits, first=first)  # uniform in [0,2^bits), not reduced
-    d_scal = torch.from_numpy(scal).cuda()
-    torch.cuda.synchronize()
-
-    # One step = one complete MSM.  Two steps are kept in flight: the GPU work of step i+1 is enqueued before the
-    # host tail of step i (Horner over windows, affine normalisation, partial-sum exchange) runs, so the GPU never
-    # waits for the CPU.  Every step's result is produced inside the timed region.
-    def submit():
-        return eng.submit(curve, d_scal, d_points, n)
-
-    # N > 1: the all_gather of the partials is started when a step's local MSM is done and completed one step later, so its
-    # latency hides under the next MSM (every exchange still starts and ends inside the timed region)
-    xchg = parallel.ShardExchange(curve)
 
     def fence():
         if world > 1:
@@ -274,51 +270,106 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    def run_steps(k, acc=None):
-        res = None
-        pending = submit() if k > 0 else None
-        in_exchange = None
-        for i in range(k):
-            nxt = submit() if i + 1 < k else None
-            part = eng.finish(pending, coord="aff")
-            started = xchg.start(part)
+    def timed_leg(leg_strong, lg, exchange=True, solo=False):
+        """One timed loop: `steps` complete MSMs with two in flight.  leg_strong: 2^lg pairs in total over the ranks, else 2^lg per
+        rank.  solo: this rank alone, all 2^lg pairs, no collective (the same-run one-GPU reference of an N-GPU line).
+        exchange=False: every rank its shard, no collective and no barrier (what the exchange and the barrier cost)."""
+        if solo:
+            leg_first, leg_n, leg_total = 0, 1 << lg, 1 << lg
+        elif leg_strong:
+            leg_total = 1 << lg
+            leg_first, leg_n = parallel.shard_bounds(leg_total, world, rank)     # balanced contiguous slices (partitioners.nim:44-77)
+        else:
+            leg_n = 1 << lg
+            leg_total, leg_first = world * leg_n, rank * leg_n
+        # ... and below 2^20 pairs only every fourth MSM carries the events (four records cost a 0.5 ms step 12 %: 2^16 0.53 ms per step
+        # against 0.47 without); the kernel's average duration is then over those launches of the timed region
+        eng.set_option("timings_every", 1 if leg_n >= (1 << 20) else 4)
+        # ---- synthetic inputs, resident in HBM -----------------------------------------------------------
+        d_points = torch.empty((leg_n, info.aff_bytes), dtype=torch.uint8, device="cuda")
+        eng.gen_points(curve, seed, leg_n, d_points, first=leg_first)            # P_i = [s_i]G, uniform over the subgroup
+        scal = synth_scalars(seed + 1, leg_n, info.scalar_bits, first=leg_first)  # uniform in [0,2^bits), not reduced
+        d_scal = torch.from_numpy(scal).cuda()
+        torch.cuda.synchronize()
+        collective = exchange and not solo
+        # N > 1: the all_gather of the partials is started when a step's local MSM is done and completed one step later, so its
+        # latency hides under the next MSM (every exchange still starts and ends inside the timed region)
+        xchg = parallel.ShardExchange(curve) if collective else None
+
+        # One step = one complete MSM.  Two steps are kept in flight: the GPU work of step i+1 is enqueued before the
+        # host tail of step i (Horner over windows, affine normalisation, partial-sum exchange) runs, so the GPU never
+        # waits for the CPU.  Every step's result is produced inside the timed region.
+        def run_steps(k, acc=None):
+            res = None
+            pending = eng.submit(curve, d_scal, d_points, leg_n) if k > 0 else None
+            in_exchange = None
+            for i in range(k):
+                nxt = eng.submit(curve, d_scal, d_points, leg_n) if i + 1 < k else None
+                part = eng.finish(pending, coord="aff")
+                if xchg is None:
+                    res = part
+                else:
+                    started = xchg.start(part)
+                    if in_exchange is not None:
+                        res = xchg.finish(in_exchange)
+                    in_exchange = started
+                if acc is not None:
+                    t = eng.last_timings()                      # HIP events recorded on the engine's stream (zeros: not a sampled step)
+                    if t["total"] > 0.0:
+                        for key, v in t.items():
+                            acc[key] = acc.get(key, 0.0) + v
+                        acc["_launches"] = acc.get("_launches", 0) + 1
+                pending = nxt
             if in_exchange is not None:
                 res = xchg.finish(in_exchange)
-            in_exchange = started
-            if acc is not None:
-                t = eng.last_timings()                      # HIP events recorded on the engine's stream (zeros: not a sampled step)
-                if t["total"] > 0.0:
-                    for key, v in t.items():
-                        acc[key] = acc.get(key, 0.0) + v
-                    acc["_launches"] = acc.get("_launches", 0) + 1
-            pending = nxt
-        if in_exchange is not None:
-            res = xchg.finish(in_exchange)
-        return res
+            return res
 
-    run_steps(args.warmup)
-    stage_acc = {}
-    fence()
-    t0 = time.perf_counter()
-    res = run_steps(args.steps, stage_acc)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        def local_fence():
+            torch.cuda.synchronize()
+            eng.sync()
+        fn_fence = fence if collective else local_fence
+        run_steps(args.warmup)
+        acc = {}
+        fn_fence()
+        t0 = time.perf_counter()
+        res = run_steps(args.steps, acc)
+        fn_fence()
+        dt = time.perf_counter() - t0
+        if collective and world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        launches = int(acc.pop("_launches", 0))
+        return {"n": leg_n, "first": leg_first, "total": leg_total, "dt": dt, "res": res, "plan": eng.last_plan(),
+                "stages": {k: v / max(1, launches) for k, v in acc.items()}, "ev_launches": launches,
+                "scal": scal, "d_points": d_points, "d_scal": d_scal}
 
-    plan = eng.last_plan()
-    ev_launches = int(stage_acc.pop("_launches", 0))
-    stages = {k: v / max(1, ev_launches) for k, v in stage_acc.items()}
+    def ranks_seen():
+        # what the collective library reports, not what the launcher asked for: every rank contributes 1
+        ones = torch.ones(1, dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        return int(ones.item())
+
+    def leg_summary(leg, leg_strong, lg):
+        return {"value": leg["total"] * args.steps / leg["dt"], "unit": "points/s", "ms_per_step": leg["dt"] / args.steps * 1e3,
+                "scaling": "strong" if leg_strong else "weak", "total_pairs": leg["total"], "pairs_per_gpu_rank0": leg["n"],
+                "window_bits": leg["plan"]["c"], "windows": leg["plan"]["W"], "entries_per_lane": leg["plan"]["K"],
+                "rccl_ranks_seen": ranks_seen(),
+                "workload": f"{curve} MSM, 2^{lg} pairs " + ("in total" if leg_strong else "per GPU") + f", {world} ranks, inputs resident in HBM, two MSMs in flight"}
+
+    lg = main_total_log2 if strong else args.log2n
+    leg = timed_leg(strong, lg)
+    n, first, total, dt, res, plan, stages = leg["n"], leg["first"], leg["total"], leg["dt"], leg["res"], leg["plan"], leg["stages"]
+    scal, d_points, d_scal, ev_launches = leg["scal"], leg["d_points"], leg["d_scal"], leg["ev_launches"]
     value = total * args.steps / dt
-    lg = args.total_log2n if strong else args.log2n
     label = BASELINE_CONFIG.get((curve, lg, world)) if not strong else ("configs[3]" if (curve, lg, world) == ("bls12_381_g1", 24, 8) else None)
+    if strong and curve == "bls12_381_g1" and lg == 20:
+        label = "the metric: 2^20 pairs at 1/2/4/8 GPUs"
 
     out = {
-        "metric": ("MSM points/sec, BLS12-381 G1, 2^20 random pairs" if (curve == "bls12_381_g1" and lg == 20 and not strong)
+        "metric": ("MSM points/sec, BLS12-381 G1, 2^20 random pairs" if (curve == "bls12_381_g1" and lg == 20 and (strong or world == 1))
                    else f"MSM points/sec, {curve}, 2^{lg} random pairs")
-                  + (" in total" if strong else f" per GPU ({world} x 2^{lg} pairs in one MSM)" if world > 1 else "")
+                  + (f" in total over {world} GPUs" if strong else f" per GPU ({world} x 2^{lg} pairs in one MSM)" if world > 1 else "")
                   + "; pipelined throughput, 2 MSMs in flight, inputs resident in HBM",
         "value": value,
         "value_kind": "pipelined: steps / wall time with two complete MSMs in flight (the host tail of MSM i runs under the GPU work of "
@@ -337,7 +388,7 @@ def main():
         "config": {
             "workload": (f"{curve} MSM, 2^{lg} (scalar,point) pairs " + ("in total" if strong else "per GPU")
                          + ", inputs resident in HBM, two MSMs in flight" + (f" (BASELINE.json {label})" if label else "")),
-            "pairs_per_gpu": n, "total_pairs": total, "scalar_bits": info.scalar_bits,
+            "pairs_per_gpu": n, "total_pairs": total, "ranks": world, "scalar_bits": info.scalar_bits,
             "window_bits": plan["c"], "windows": plan["W"], "entries_per_lane": plan["K"],
             "sharding": f"points x{world}, asynchronous all_gather of one affine point per rank ({args.backend}), completed one step later, + host sum" if world > 1 else "none",
             "seed": seed,
@@ -349,10 +400,65 @@ def main():
     if world > 1:
         # what the collective library reports, not what the launcher asked for: the first RCCL/gloo collective of the run was the
         # barrier of the first fence(); here every rank contributes 1 and rank 0 prints the sum next to the backend's own count
-        ones = torch.ones(1, dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        out["collective"] = {"backend": dist.get_backend(), "rccl_ranks_seen": int(ones.item()), "world_size": dist.get_world_size(),
+        out["collective"] = {"backend": dist.get_backend(), "rccl_ranks_seen": ranks_seen(), "world_size": dist.get_world_size(),
                              "devices": torch.cuda.device_count(), "rank0_device": torch.cuda.get_device_name(local_rank)}
+        # ---- what bounds the split (same run, same boxes): (a) every rank its shard with no exchange and no barrier -- what the
+        # all_gather of one point per rank and the host sum cost on top of the slowest rank's MSMs; (b) rank 0 alone on ALL the pairs --
+        # the one-GPU figure the N-GPU line is a speed-up over (the other ranks wait at the barrier)
+        if strong:
+            own = timed_leg(True, lg, exchange=False)
+            t = torch.tensor([own["dt"]], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            own_ms = float(t.item()) / args.steps * 1e3
+            solo_ms = None
+            if rank == 0 and lg <= 22:
+                solo = timed_leg(True, lg, solo=True)
+                solo_ms = solo["dt"] / args.steps * 1e3
+            dist.barrier()
+            out["strong_bound"] = {
+                "ms_per_step_shards_without_exchange": own_ms,
+                "ms_per_step_one_gpu_same_run": solo_ms,
+                "speedup_vs_one_gpu_same_run": (solo_ms / (dt / args.steps * 1e3)) if solo_ms else None,
+                "speedup_bound_from_shard_time": (solo_ms / own_ms) if solo_ms else None,
+                "note": "2^%d / %d pairs per rank: a small MSM is a chain of dependent launches (DESIGN.md section 6: 2.9 / 1.7 / 1.0 / 0.65 ms for "
+                        "2^20 / 2^19 / 2^18 / 2^17 pairs on one GPU), so the split of a FIXED 2^20-pair job is bounded well below N x" % (lg, world)}
+        # ---- the other forms of the same job, same run (driver form only: `--gpus N` with no size flag) --------------------------
+        if driver_form:
+            w = timed_leg(False, 20)
+            out["weak_2pow20_per_gpu"] = leg_summary(w, False, 20)
+            if world == 8 and curve == "bls12_381_g1":
+                c3 = timed_leg(True, 24)
+                out["configs3_2pow24_total"] = leg_summary(c3, True, 24)
+                out["configs3_2pow24_total"]["baseline_config"] = "BASELINE.json configs[3]"
+        # ---- the in-library form: ONE process calls the Constantine symbol on host arrays, the library shards the call over the GPUs
+        # (ctt_hip_msm_set_devices; what a Constantine caller on an 8-GPU node gets without a source change).  Rank 0 only, the other
+        # ranks wait; PCIe included, never `value`.
+        if strong and not args.no_latency and args.all_ranks_on_device < 0:
+            if rank == 0:
+                from constantine_amd import multiScalarMul_vartime, multiScalarMul_vartime_parallel
+                from constantine_amd.msm import set_devices
+                full = 1 << lg
+                h_points = torch.empty((full, info.aff_bytes), dtype=torch.uint8, device="cuda")
+                eng.gen_points(curve, seed, full, h_points, first=0)
+                pts_host = h_points.cpu().numpy()
+                sc_host = synth_scalars(seed + 1, full, info.scalar_bits, first=0)
+                fn = (lambda s_, p_: multiScalarMul_vartime_parallel(None, curve, s_, p_, coord="jac")) if info.has_parallel \
+                    else (lambda s_, p_: multiScalarMul_vartime(curve, s_, p_, coord="jac"))
+                res_h = {}
+                for tag, devs in (("one_device", [local_rank]), ("all_devices", list(range(torch.cuda.device_count())))):
+                    set_devices(devs if len(devs) > 1 else [])
+                    hp = []
+                    for _ in range(7):
+                        t1 = time.perf_counter()
+                        fn(sc_host, pts_host)
+                        hp.append((time.perf_counter() - t1) * 1e3)
+                    res_h[tag] = statistics.median(hp[2:])
+                set_devices([])
+                out["hostptr_sharded_ms"] = {"one_device": res_h["one_device"], "all_devices": res_h["all_devices"],
+                                             "devices": torch.cuda.device_count(),
+                                             "note": f"median of 5 calls of the Constantine symbol on pageable host arrays, 2^{lg} pairs, from ONE process "
+                                                     "(rank 0; the other ranks idle): the library's own sharding over the node's GPUs, PCIe included"}
+            dist.barrier()
 
     if rank == 0:
         # ---- roofline of the dominant kernel (bucket accumulation, k_accum); N > 1: rank 0's launches (every rank runs the same
@@ -360,12 +466,23 @@ def main():
         t_acc = stages.get("accumulate", 0.0) * 1e-3
         alg_bytes = n * BYTES_PER_PAIR.get(curve, 128)  # N x (scalar + affine point), one launch = all windows
         achieved = alg_bytes / t_acc / 1e9 if t_acc > 0 else 0.0
+        # HBM traffic of the kernel: rocprofv3 --pmc passes of the same command (tools/collect_round.sh), kept in profiles/ -- counters
+        # cannot be collected from inside the run they annotate.  The file records the digest of the kernel sources it was measured
+        # on; a figure measured on other sources is refused (traffic: null) rather than quoted.
         traffic, traffic_src = None, None
         tr_path = os.path.join(ROOT, "profiles", "hbm_traffic_k_accum.json")
         if os.path.exists(tr_path):
             try:
-                traffic = json.load(open(tr_path)).get(f"{curve}_2^{int(np.log2(n)) if n & (n - 1) == 0 else -1}")
-                traffic_src = "profiles/hbm_traffic_k_accum.json (rocprofv3 --pmc passes of an earlier run of this workload, not measured in this run)"
+                doc = json.load(open(tr_path))
+                key = f"{curve}_2^{int(np.log2(n)) if n & (n - 1) == 0 else -1}"
+                have, now = doc.get("_sources_sha256"), kernel_sources_digest()
+                if key in doc and have == now:
+                    traffic = doc[key]
+                    traffic_src = (f"profiles/hbm_traffic_k_accum.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on the "
+                                   f"same kernel sources (sha256 {now[:12]}, collected {doc.get('_collected', '?')}), not measured in this run")
+                elif key in doc:
+                    traffic_src = (f"profiles/hbm_traffic_k_accum.json holds {doc[key]} B per launch, measured on kernel sources {str(have)[:12]} -- "
+                                   f"this tree is {now[:12]}: refused as stale")
             except Exception:
                 traffic = None
         out["roofline"] = {
@@ -382,7 +499,7 @@ def main():
                 "frac_vs_round1_peak_31T": mads / t_acc / INT_MAD_PEAK_R01,
                 "note": "the multiply-adds are ~78 % of the kernel's VALU instructions; every VOP3 instruction issues at the same "
                         "~4.5 cycles per wave (profiles/microbench_isa_r02.jsonl), so the kernel's own roof is its instruction "
-                        "count: profiles/pmc_r04_sq_counters_k_accum_*.txt: 4558 VALU instructions per mixed addition for 3542 multiply-adds (DESIGN.md 4.3 has the account per class)",
+                        "count: profiles/pmc_r05_sq_counters_k_accum_*.txt: 4558 VALU instructions per mixed addition for 3542 multiply-adds (DESIGN.md 4.3 has the account per class)",
             }
 
     # ---- the reference bench's own definition: one blocking call per iteration ----------------------------
@@ -478,8 +595,8 @@ def main():
             out["cpu_baseline"] = {
                 "value": m / cpu_dt, "unit": "points/s", "cores": cores, "kind": "port",
                 "sample": f"first 2^{int(np.log2(m))} pairs of the same workload, oracle/msm_ref.cpp "
-                          f"(restatement of Constantine's Pippenger with its batched-affine buckets, not Constantine: no endomorphism, "
-                          f"no assembly), c={c_used}, median of 3 runs "
+                          f"(restatement of Constantine's Pippenger with its batched-affine buckets and its endomorphism pre-split "
+                          f"where the reference's dispatch applies it -- not at this size --, not Constantine: C++ instead of its assembly), c={c_used}, median of 3 runs "
                           f"({', '.join(f'{r:.2f}' for r in runs)} s wall), "
                           f"{cores} threads on a {budget}-CPU cgroup quota ({os.cpu_count()} logical CPUs visible, {cpu_model()}); {flags}",
             }

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTT_MSM_HIP_LIB") or os.path.join(HERE, "libctt_msm_hip.so")
 
 _lib = None
-ABI_VERSION = 8  # ctt_hip_msm_abi_version() of the library this package was written against
+ABI_VERSION = 9  # ctt_hip_msm_abi_version() of the library this package was written against
 
 
 class HipLibraryMissing(RuntimeError):
@@ -31,7 +31,7 @@ def exported_symbols():
              "ctt_hip_msm_with_bases", "ctt_hip_msm_with_bases_submit", "ctt_hip_msm_bases_create_table", "ctt_hip_msm_bases_window_bits", "ctt_hip_msm_last_timings", "ctt_hip_msm_last_plan", "ctt_hip_gen_points",
              "ctt_hip_field_op", "ctt_hip_ec_sum_affine", "ctt_hip_msm_stream", "ctt_hip_msm_wait_stream",
              "ctt_hip_msm_set_devices", "ctt_hip_msm_set_shard_min", "ctt_hip_subgroup_check", "ctt_hip_fr_quotient",
-             "ctt_hip_msm_host", "ctt_hip_msm_available",
+             "ctt_hip_msm_host", "ctt_hip_msm_available", "ctt_hip_last_error", "ctt_hip_last_error_message", "ctt_hip_clear_last_error",
              # part 3: the MSM's callers under the reference's names + their host-only pieces
              "ctt_eth_kzg_context_new", "ctt_eth_kzg_context_new_with_precompute", "ctt_eth_kzg_context_delete", "ctt_eth_kzg_blob_to_kzg_commitment", "ctt_eth_kzg_compute_kzg_proof",
              "ctt_eth_kzg_compute_blob_kzg_proof", "ctt_eth_kzg_blob_to_kzg_commitment_parallel", "ctt_eth_kzg_compute_kzg_proof_parallel",
@@ -39,6 +39,21 @@ def exported_symbols():
              "ctt_hip_eth_kzg_context_from_srs", "ctt_hip_sha256", "ctt_hip_bls12_381_g1_decompress", "ctt_hip_bls12_381_g1_compress",
              "ctt_hip_eth_kzg_blob_to_scalars", "ctt_hip_eth_kzg_challenge", "ctt_hip_eth_kzg_quotient_host"]
     return syms
+
+
+GPU_UNAVAILABLE = 0xF0   # CTT_HIP_STATUS_GPU_UNAVAILABLE: what a protocol symbol returns when the GPU cannot serve the call
+
+
+class GpuUnavailable(RuntimeError):
+    """A call the GPU could not serve (no device, out of device memory, a failed HIP call, both in-flight slots taken): the
+    library reports it through the call's return value; `code` / the message are ctt_hip_last_error() / _message() of this thread.
+    There is no CPU path inside the library -- what to do instead is the caller's decision."""
+
+    def __init__(self, what=""):
+        L = lib()
+        self.code = int(L.ctt_hip_last_error())
+        msg = L.ctt_hip_last_error_message()
+        super().__init__(f"{what}: GPU unavailable ({self.code}): {msg.decode(errors='replace') if msg else ''}")
 
 
 def _share_hip_runtime_with_torch():
@@ -102,6 +117,13 @@ def lib():
         L.ctt_hip_msm_host.restype = i32
         L.ctt_hip_msm_available.argtypes = []
         L.ctt_hip_msm_available.restype = i32
+    if "ctt_hip_last_error" not in missing:
+        L.ctt_hip_last_error.argtypes = []
+        L.ctt_hip_last_error.restype = i32
+        L.ctt_hip_last_error_message.argtypes = []
+        L.ctt_hip_last_error_message.restype = ctypes.c_char_p
+        L.ctt_hip_clear_last_error.argtypes = []
+        L.ctt_hip_clear_last_error.restype = None
     if "ctt_eth_kzg_context_new" not in missing:
         u8 = ctypes.c_uint8   # the reference's status enums are __attribute__((__packed__)): one byte
         L.ctt_eth_kzg_context_new.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, u8]

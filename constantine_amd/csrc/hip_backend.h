@@ -4,18 +4,17 @@
 #include <hip/hip_runtime.h>
 
 #include "generators.h"
+#include "hip_errors.h"
 #include "msm_pipeline.h"
 
 namespace ctt {
 
+// a failed HIP call is reported through the entry point's return value where there is one, and aborts where there is none (hip_errors.h)
 #define HIP_CHECK(expr)                                                                              \
   do {                                                                                               \
     hipError_t e_ = (expr);                                                                          \
-    if (e_ != hipSuccess) {                                                                          \
-      fprintf(stderr, "[ctt_msm_hip] FATAL %s:%d: %s -> %s\n", __FILE__, __LINE__, #expr,            \
-              hipGetErrorString(e_));                                                                \
-      abort();                                                                                       \
-    }                                                                                                \
+    if (e_ != hipSuccess)                                                                            \
+      ::ctt::hip_failed(#expr, hipGetErrorString(e_), e_ == hipErrorOutOfMemory, __FILE__, __LINE__); \
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
@@ -125,6 +124,25 @@ template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_merge_final(MergeArgs<F> a) {
   if (merge_chain_bound<F>(a) <= 1) return;   // the tail merge wrote the buckets
   merge_final_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// queue form of the head merge (msm_bodies.h merge_tail_queue_body): the tail merge; the first heads of the chains with work left
+// go to the queue with ONE atomic per wave (ballot + prefix count; a workgroup is one wave)
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_tail_queue(MergeArgs<F> a) {
+  uint32_t item = 0;
+  const bool more = merge_tail_queue_body<F>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, &item);
+  const uint64_t mask = __ballot(more);
+  if (mask == 0) return;
+  uint32_t base = 0;
+  const uint32_t lane = threadIdx.x & 63u;
+  if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) base = atomicAdd(a.qcount, (uint32_t)__popcll(mask));
+  base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+  if (more) a.queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = item;
+}
+// one lane per queued chain; the grid covers the queue's capacity, the lanes beyond its count leave at once
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_queue(MergeArgs<F> a, uint32_t lmax) {
+  merge_queue_body<F>(a, blockIdx.x * blockDim.x + threadIdx.x, lmax);
 }
 template <class F>
 __global__ void __launch_bounds__(EC_BLOCK) k_pyr(PyrArgs<F> a, uint32_t ntasks) {
@@ -335,6 +353,11 @@ static constexpr int RED_BLOCK = 256;
 template <class F>
 __global__ void __launch_bounds__(RED_BLOCK) k_merge_finish(MergeArgs<F> a, uint32_t first_d) {
   merge_finish_body<F>(a, blockIdx.x, first_d, threadIdx.x, blockDim.x, []() { __syncthreads(); });
+}
+// the chains the chain form left (more than lmax heads: unusual inputs), one workgroup per window (msm_bodies.h merge_long_body)
+template <class F>
+__global__ void __launch_bounds__(RED_BLOCK) k_merge_long(MergeArgs<F> a, uint32_t lmax) {
+  merge_long_body<F>(a, blockIdx.x, lmax, threadIdx.x, blockDim.x, []() { __syncthreads(); });
 }
 // head-merge tree step with four lanes per addition (a step has at most G / 2d additions per window)
 template <class F>
@@ -647,6 +670,22 @@ struct HipBackend {
     hipLaunchKernelGGL(k_merge_finish<F>, dim3(W), dim3(RED_BLOCK), 0, cur(), a, first_d);
     HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_merge_final<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F>
+  void launch_merge_tail_queue(const MergeArgs<F>& a, uint32_t W) {
+    hipLaunchKernelGGL(k_merge_tail_queue<F>, grid2(a.G, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F>
+  void launch_merge_queue(const MergeArgs<F>& a, uint32_t W, uint32_t lmax) {
+    // at most every second lane starts a chain of two or more heads
+    hipLaunchKernelGGL(k_merge_queue<F>, grid1(merge_queue_capacity(W, a.G), EC_BLOCK), dim3(EC_BLOCK), 0, cur(), a, lmax);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <class F>
+  void launch_merge_long(const MergeArgs<F>& a, uint32_t W, uint32_t lmax) {
+    hipLaunchKernelGGL(k_merge_long<F>, dim3(W), dim3(RED_BLOCK), 0, cur(), a, lmax);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>

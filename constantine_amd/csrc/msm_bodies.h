@@ -161,6 +161,12 @@ struct SortArgs {
   uint32_t cap, big;        // k_group_sort: entries per LDS tile; buckets above `big` bypass the LDS image
   uint32_t xcd_map = 1;     // partition kernels: neighbouring slices on one XCD (msm_engine.hip part_slice_of_block); 0 = slice b to block b
   uint32_t staged = 1;      // pass A sweep 2 through an LDS image of the block's output (k_part_scatter_staged); 0 = one store per record
+  // Round 5: the sort clears the EMPTY buckets of the set it sorts for (zero_bytes = bytes of one bucket, [W][B] buckets at
+  // zero_base; 0 = leave them alone).  The accumulation and the head merge write every non-empty bucket, so this is all of the
+  // "bucket set = neutral" that the accumulation needs -- rounds 1-4 cleared the whole set with a fill launch between the sort and
+  // the accumulation (8 us + a launch gap of a 2^16-pair MSM's chain).
+  void* zero_base = nullptr;
+  uint32_t zero_bytes = 0;
 };
 
 // Fr Montgomery -> canonical (batchFromField, finite_fields.nim:915-920)
@@ -469,6 +475,8 @@ struct MergeArgs {
   const uint32_t* tkey;
   const uint32_t* maxcount;  // device word: largest bucket size over all windows
   uint32_t B, K, G;
+  uint32_t* queue = nullptr;   // queue form (merge_tail_queue_body): first-head slots of the chains with more than one head, [merge_queue_capacity]
+  uint32_t* qcount = nullptr;  // entries in the queue (zeroed before the tail merge)
 };
 
 // longest possible chain of heads: a bucket of m entries spans at most floor((m-1)/K)+1 lanes (maxcount = the largest
@@ -542,6 +550,93 @@ CTT_HD void merge_finish_body(const MergeArgs<F>& a, uint32_t w, uint32_t first_
   for (uint32_t d = first_d; d < chain; d <<= 1) {
     for (uint32_t g = lane; g < a.G; g += nlanes) merge_step_body<F>(a, w, g, d);
     sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Queue form of the head merge (round 5).  The tree above costs a launch per level -- tail merge, log2(chain) steps, the
+// finishing launch, the final copy: six launches and 120-130 us for a 2^16-pair MSM whose chains hold one to three heads (K = 11
+// entries per lane, ~16 per bucket) -- and every level behind the first is a grid of G lanes (4 G in the quad form) of which a few
+// per wave have an addition to do: the first tree step alone took 46 us for 36 k additions.  When the plan expects SHORT chains:
+//   launch 1  merge_tail_queue_body: the tail merge, heads[s] += tails[s-1] (dense: nearly every lane has a tail).  A chain of ONE
+//             head is finished -- the sum goes to the bucket (the tree form only knew that when NO chain of the MSM was longer);
+//             the first head of a longer chain is appended to a queue (one atomic per wave);
+//   launch 2  merge_queue_body: one lane per queued chain adds the heads s .. e one after the other -- dense again, since the
+//             queue holds nothing but chains with work left, and two or three additions deep;
+//   launch 3  merge_long_body (one workgroup per window) takes the chains longer than `lmax` heads -- skewed digit
+//             distributions, "all scalars equal" -- as a tree; it returns at once when the largest bucket says there is none.
+// (Measured first, same box: ONE launch in which the lane of a chain's first head walks tail + all heads -- every wave then runs
+// as long as its longest chain with a third of its lanes idle from the start: 130-140 us at 2^16 against the tree's 118-123.)
+// ---------------------------------------------------------------------------------------------
+// first / last lane that holds a head of bucket b (b straddles lane ranges): the tail sits in lane s - 1
+CTT_HD uint32_t chain_first(const uint32_t* bs, uint32_t K, uint32_t b) { return bs[b] / K + 1; }
+CTT_HD uint32_t chain_last(const uint32_t* bs, uint32_t K, uint32_t b) { return (bs[b + 1] - 1) / K; }
+
+// capacity of the queue: a chain of two or more heads takes two lanes, so at most every second lane of a window starts one
+CTT_HD uint32_t merge_queue_capacity(uint32_t W, uint32_t G) { return W * (G / 2u + 1u); }
+
+// lane g: the tail merge.  Returns true when the chain that starts in lane g + 1 has more than one head: *item = its first
+// head's slot, for the queue (the caller appends it: wave-aggregated on the GPU).
+template <class F>
+CTT_HD bool merge_tail_queue_body(const MergeArgs<F>& a, uint32_t w, uint32_t g, uint32_t* item) {
+  if (g + 1 >= a.G) return false;
+  const uint64_t slot = (uint64_t)w * a.G + g;
+  const uint32_t b = a.tkey[slot];
+  if (b == KEY_NONE) return false;
+  const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
+  const XYZZ<F> h = a.heads[slot + 1], t = a.tails[slot];
+  const XYZZ<F> r = xyzz_add_inl<F>(h, t);
+  const bool more = chain_last(bs, a.K, b) > g + 1;
+  if (more) {
+    a.heads[slot + 1] = r;
+    *item = (uint32_t)(slot + 1);
+  } else {
+    a.buckets[(uint64_t)w * a.B + b] = r;
+  }
+  return more;
+}
+
+// queue entry qi: the rest of a chain of 2 .. lmax heads (the tail is in its first head already)
+template <class F>
+CTT_HD void merge_queue_body(const MergeArgs<F>& a, uint32_t qi, uint32_t lmax) {
+  if (qi >= *a.qcount) return;
+  const uint32_t slot = a.queue[qi];
+  const uint32_t w = slot / a.G, s = slot - w * a.G;
+  const uint32_t b = a.hkey[slot];
+  const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
+  const uint32_t len = chain_last(bs, a.K, b) - s + 1;
+  if (len > lmax) return;                       // merge_long_body's
+  XYZZ<F> r = a.heads[slot];
+  for (uint32_t i = 1; i < len; i++) {
+    const XYZZ<F> h = a.heads[slot + i];
+    r = xyzz_add_inl<F>(r, h);
+  }
+  a.buckets[(uint64_t)w * a.B + b] = r;
+}
+
+// the chains merge_queue_body left (more than lmax heads; their tails are merged), one workgroup per window: the tree over
+// the heads, then the chain heads into the buckets, with a workgroup barrier (`sync`) between the levels
+template <class F, class Sync>
+CTT_HD void merge_long_body(const MergeArgs<F>& a, uint32_t w, uint32_t lmax, uint32_t lane, uint32_t nlanes, Sync&& sync) {
+  const uint32_t chain = merge_chain_bound<F>(a);
+  if (chain <= lmax) return;                    // (uniform: every lane reads the same word)
+  const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
+  auto is_long = [&](uint32_t b) { return chain_last(bs, a.K, b) - chain_first(bs, a.K, b) + 1 > lmax; };
+  for (uint32_t d = 1; d < chain; d <<= 1) {
+    for (uint32_t g = lane; g < a.G; g += nlanes) {
+      if (!merge_step_active<F>(a, w, g, d)) continue;
+      const uint64_t slot = (uint64_t)w * a.G + g;
+      if (!is_long(a.hkey[slot])) continue;
+      const XYZZ<F> x = a.heads[slot], y = a.heads[slot + d];
+      a.heads[slot] = xyzz_add_inl<F>(x, y);
+    }
+    sync();
+  }
+  for (uint32_t g = lane; g < a.G; g += nlanes) {
+    const uint64_t slot = (uint64_t)w * a.G + g;
+    const uint32_t b = a.hkey[slot];
+    if (b == KEY_NONE || g != chain_first(bs, a.K, b) || !is_long(b)) continue;
+    a.buckets[(uint64_t)w * a.B + b] = a.heads[slot];
   }
 }
 

@@ -42,6 +42,7 @@ struct MsmPlan {
   uint32_t id_stride;  // table rows per window (the cached bases' length; a call may use a prefix)
   int h, ngrp;         // bit Horner: bits per group, groups per window (the device returns W*ngrp partial sums)
   int merge_steps;     // wide head-merge tree steps enqueued without knowing the largest bucket (plan_merge_steps)
+  uint32_t merge_lmax; // > 0: the queue form of the head merge (msm_bodies.h merge_tail_queue_body) for chains of at most this many heads; 0: the tree
 };
 
 struct MsmOptions {
@@ -63,6 +64,9 @@ struct MsmOptions {
   // that also serves more than 1024 groups).  Options "sort_xcd" / "sort_staged", $CTT_SORT_XCD / $CTT_SORT_STAGED.
   int sort_xcd = 1, sort_staged = 1;
   int early_tail = 1;   // MsmEngine::submit: merge + every reduction pass on the tail stream for large pipelined MSMs (0 off, 1 automatic, 2 always)
+  // head merge: 0 = the queue form (tail merge + one lane per chain with work left, msm_bodies.h merge_tail_queue_body) when the plan
+  // expects chains of at most merge_lmax heads, else the tree; 1 = the queue form always; 2 = the tree always.  merge_lmax 0 = 8.
+  int merge_chain = 0, merge_lmax = 0;
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -168,6 +172,16 @@ static inline int plan_merge_steps(const MsmPlan& p, int bits) {
   while (chain > 1.0 && steps < 31) { chain *= 0.5; steps++; }
   return steps;
 }
+// Queue form or tree (MsmPlan::merge_lmax)?  What is left of a chain behind its tail merge is walked by ONE lane, so the form pays while the chains an ordinary digit
+// distribution produces are short: the same bound as plan_merge_steps (2^steps >= heads of the fullest ordinary bucket) against
+// lmax.  Plans with tiny K against full buckets (a 4096-point commitment over a window table: K = 4, ~90 entries per bucket, chains
+// of 20 heads) keep the tree; so does sum_reduce, whose single bucket spans every lane.
+static inline uint32_t plan_merge_lmax(const MsmPlan& p, const MsmOptions& o) {
+  const uint32_t lmax = o.merge_lmax > 0 ? (uint32_t)o.merge_lmax : 8u;
+  if (o.merge_chain == 1) return lmax;
+  if (o.merge_chain == 2) return 0u;
+  return (p.merge_steps <= 30 && (1u << p.merge_steps) <= lmax) ? lmax : 0u;
+}
 
 static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   MsmPlan p;
@@ -224,6 +238,7 @@ static inline MsmPlan make_plan(uint32_t n, int bits, const MsmOptions& o) {
   p.id_stride = 0;
   plan_horner(p, o);
   p.merge_steps = plan_merge_steps(p, bits);
+  p.merge_lmax = plan_merge_lmax(p, o);
   return p;
 }
 
@@ -307,6 +322,7 @@ static inline MsmPlan make_table_plan(uint32_t n, int bits, int c, uint32_t ntab
   p.G = (p.nent + K - 1) / K;
   plan_horner(p, o);
   p.merge_steps = plan_merge_steps(p, bits);
+  p.merge_lmax = plan_merge_lmax(p, o);
   return p;
 }
 
@@ -367,11 +383,11 @@ struct MsmEngine {
   struct Buf { void* p = nullptr; size_t cap = 0; };
   // bstartS / maxcountS / bucketsS: one per in-flight slot -- the head merge and the first reduction pass of MSM i read them on the tail
   // stream while the sort of MSM i+1 already writes its own (submit(): early tail)
-  Buf part, counts, bstartS[2], entries, bucketsS[2], heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcountS[2], cpoints, totals, gbase;
+  Buf part, counts, bstartS[2], entries, bucketsS[2], heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcountS[2], cpoints, totals, gbase, mqueue;
 
   explicit MsmEngine(BK& b) : bk(b) {}
   ~MsmEngine() {
-    Buf* all[] = {&part, &gbase, &counts, &bstartS[0], &bstartS[1], &entries, &bucketsS[0], &bucketsS[1], &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcountS[0], &maxcountS[1], &cpoints, &totals};
+    Buf* all[] = {&part, &gbase, &counts, &bstartS[0], &bstartS[1], &entries, &bucketsS[0], &bucketsS[1], &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcountS[0], &maxcountS[1], &cpoints, &totals, &mqueue};
     for (Buf* b : all) if (b->p) bk.free(b->p);
     for (Slot& sl : slots) if (sl.hraw) bk.free_host(sl.hraw);
   }
@@ -495,6 +511,7 @@ struct MsmEngine {
     need(tails, W * p.G * sizeof(XYZZ<FD>));
     need(hkey, W * p.G * 4);
     need(tkey, W * p.G * 4);
+    if (p.merge_lmax > 0) need(mqueue, (size_t)merge_queue_capacity(p.W, p.G) * 4);
   }
   // points_arrive (submit_host, a slice copied by the submitting thread): the points of this slice are not on the device yet -- the
   // digits and the sort need the coefficients only, so they are enqueued first, the hook then copies the points (the thread sits in that
@@ -546,8 +563,13 @@ struct MsmEngine {
     st.d_bstart = (uint32_t*)need(bstartS[sl], (size_t)W * (B + 1) * 4);
     uint32_t* d_entries = (uint32_t*)need(entries, (size_t)W * p.nent * 4);
     st.d_maxcount = (uint32_t*)need(maxcountS[sl], 256);
-    bk.memset0(st.d_maxcount, 8);
+    bk.memset0(st.d_maxcount, 16);   // [0] largest bucket, [2] the head merge's queue count
     sa.bstart = st.d_bstart; sa.entries = d_entries; sa.maxcount = st.d_maxcount;
+    // the sort leaves the empty buckets of the set neutral (round 5; a fill launch of the whole set before).  Not for a later
+    // slice of a host-pointer MSM (into): its runs continue the stored sums.  The set is this slot's: the previous MSM of the
+    // slot read it in its first reduction pass, which the accumulation before this sort waited for.
+    sa.zero_base = into ? nullptr : (void*)d_buckets;
+    sa.zero_bytes = into ? 0u : (uint32_t)sizeof(XYZZ<FD>);
     bk.launch_digits_sort(sa);   // (leaves the largest bucket in d_maxcount[0]: the merge kernels read it there)
     if (convert_late) {
       (*points_arrive)();
@@ -561,10 +583,9 @@ struct MsmEngine {
     // conversion and sort to run underneath; the accumulation must not start before it is done: k_accum takes every
     // wave slot of the chip for its whole duration, and a tail kernel enqueued behind it would wait it out (measured on
     // a slower box: reduce span 2.4 ms, the pipeline slower than the serial order).  Worst case this is the serial order.
-    // (the bucket sets are cleared before that wait: the previous MSM read them in its first reduction pass, which is ahead
-    // of this point on the main stream, and its tail does not touch them)
+    // (the sort above has left this slot's bucket set with its empty buckets neutral -- SortArgs::zero_base -- and the previous MSM
+    // runs on the other slot's set)
     // (into: a later slice of a host-pointer MSM continues the sums of the earlier slices, accum_body_xyzz)
-    if (!into) bk.memset0(d_buckets, (size_t)W * B * sizeof(XYZZ<FD>));
     // When the accumulate grid leaves wave slots free (submit() sees to that for a caller that keeps MSMs in flight: 1/16 of the
     // slots up to 2^17 pairs, 1/64 of them while that costs less than half the wait), the previous tail's narrow passes run next to it, and the wait moves to the
     // start of this MSM's reduction (reduce_buckets), the first kernel that writes what the tail still reads.
@@ -592,10 +613,20 @@ struct MsmEngine {
   void merge_buckets(int sl, const MsmPlan& p, const Staged& st) {
     bk.stage_begin(sl, ST_MERGE);
     MergeArgs<FD> ma{st.d_bstart, st.d_buckets, st.d_heads, st.d_tails, st.d_hkey, st.d_tkey, st.d_maxcount, p.B, p.K, p.G};
-    bk.template launch_merge_tail<FD>(ma, p.W);
-    uint32_t d = 1;
-    for (int i = 0; i < p.merge_steps && d < p.G; i++, d <<= 1) bk.template launch_merge_step<FD>(ma, p.W, d);
-    bk.template launch_merge_finish<FD>(ma, p.W, d);
+    if (p.merge_lmax > 0) {
+      // queue form (round 5; msm_bodies.h merge_tail_queue_body): tail merge + queue of the chains with work left, one lane per
+      // queued chain, and the long chains of unusual inputs by one workgroup per window
+      ma.queue = (uint32_t*)need(mqueue, (size_t)merge_queue_capacity(p.W, p.G) * 4);
+      ma.qcount = st.d_maxcount + 2;     // (zeroed with the largest-bucket word before the sort)
+      bk.template launch_merge_tail_queue<FD>(ma, p.W);
+      bk.template launch_merge_queue<FD>(ma, p.W, p.merge_lmax);
+      bk.template launch_merge_long<FD>(ma, p.W, p.merge_lmax);
+    } else {
+      bk.template launch_merge_tail<FD>(ma, p.W);
+      uint32_t d = 1;
+      for (int i = 0; i < p.merge_steps && d < p.G; i++, d <<= 1) bk.template launch_merge_step<FD>(ma, p.W, d);
+      bk.template launch_merge_finish<FD>(ma, p.W, d);
+    }
     bk.stage_end(sl, ST_MERGE);
   }
 

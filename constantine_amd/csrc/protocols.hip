@@ -11,6 +11,7 @@
 // the quotient polynomial of an opening (ctt_hip_fr_quotient; the branch "z is a root of unity" runs the reference's other
 // formula here on the host).  Verification needs pairings and is out of scope, like the PeerDAS cell functions.
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,12 +21,15 @@
 #endif
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <system_error>
 #include <thread>
 #include <vector>
 
 #include "host_fp64.h"
+#include "hip_errors.h"
+#include "msm_pipeline.h"   // (OutOfDeviceMemory)
 
 // (part 3 of the header declares this file's symbols with the reference's packed enums and byte-array structs; the definitions
 // below spell the same ABI with uint8_t and plain pointers, so the typed declarations stay out of this translation unit)
@@ -41,14 +45,32 @@ using FrH = Fp64<BLS12_381_Fr>;
 using Fp2H = Fp2<FpH>;
 constexpr int N_BLOB = 4096;
 
+// a failed HIP call inside a protocol symbol: recorded as the thread's last error and thrown to the symbol's boundary, which
+// returns CTT_HIP_STATUS_GPU_UNAVAILABLE -- rounds 1-4 aborted here (hip_errors.h)
 #define PROT_HIP_CHECK(x)                                                                                          \
   do {                                                                                                             \
     hipError_t e_ = (x);                                                                                           \
-    if (e_ != hipSuccess) {                                                                                        \
-      fprintf(stderr, "[ctt_msm_hip] FATAL: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
-      abort();                                                                                                     \
-    }                                                                                                              \
+    if (e_ != hipSuccess) ::ctt::hip_failed(#x, hipGetErrorString(e_), e_ == hipErrorOutOfMemory, __FILE__, __LINE__); \
   } while (0)
+
+// What a protocol symbol returns when the GPU cannot serve the call: a value outside every status enum of the reference
+// (ctt_eth_kzg_status 0..9, ctt_eth_trusted_setup_status 0..2, ctt_evm_status 0..6 -- their *_status_to_string print
+// "InvalidStatusCode" for it); ctt_hip_last_error() / _message() of the calling thread say why.  Outputs are untouched.
+constexpr uint8_t GPU_UNAVAILABLE = CTT_HIP_STATUS_GPU_UNAVAILABLE;
+
+// the body of a protocol symbol with the GPU's failures turned into that status
+template <class Fn>
+uint8_t gpu_guarded(Fn&& fn) {
+  ErrorGuard guard;
+  try {
+    return (uint8_t)fn();
+  } catch (const HipFailure&) {
+    return GPU_UNAVAILABLE;
+  } catch (const OutOfDeviceMemory& e) {
+    set_last_error(ERR_OUT_OF_MEMORY, "out of device memory (%zu bytes requested)", e.bytes);
+    return GPU_UNAVAILABLE;
+  }
+}
 
 // ---- field helpers (host, 64-bit limbs) ---------------------------------------------------------------------------------
 template <class F>
@@ -488,61 +510,64 @@ int kzg_context_build(ctt_eth_kzg_context_struct** out, const uint8_t* srs, int 
     if (status[i] != KZG_Success) return TS_InvalidFile;
   ctt_eth_kzg_context_struct* c = new ctt_eth_kzg_context_struct();
   c->device = device;
+  auto fail = [&](int st) {
+    if (c->bases) ctt_hip_msm_bases_destroy(c->hip, c->bases);
+    if (c->d_domain) (void)hipFree(c->d_domain);
+    if (c->d_poly) (void)hipFree(c->d_poly);
+    if (c->d_q) (void)hipFree(c->d_q);
+    if (c->hip) ctt_hip_msm_ctx_destroy(c->hip);
+    delete c;
+    return st;
+  };
   c->hip = ctt_hip_msm_ctx_create(device);
+  if (!c->hip) return fail(GPU_UNAVAILABLE);            // no usable device: ctt_hip_last_error() == -3
   c->own_hip = true;
   std::vector<uint8_t> ok(N_BLOB);
-  if (ctt_hip_subgroup_check(c->hip, CTT_HIP_BLS12_381_G1, ok.data(), aff.data(), N_BLOB, 0) != 0) {
-    ctt_hip_msm_ctx_destroy(c->hip);
-    delete c;
-    return TS_InvalidFile;
-  }
+  if (ctt_hip_subgroup_check(c->hip, CTT_HIP_BLS12_381_G1, ok.data(), aff.data(), N_BLOB, 0) != 0) return fail(GPU_UNAVAILABLE);
   for (int i = 0; i < N_BLOB; i++)
-    if (!ok[i]) {
-      ctt_hip_msm_ctx_destroy(c->hip);
-      delete c;
-      return TS_InvalidFile;
-    }
+    if (!ok[i]) return fail(TS_InvalidFile);
   c->bases = table ? ctt_hip_msm_bases_create_table(c->hip, CTT_HIP_BLS12_381_G1, aff.data(), N_BLOB, 0, 0)
                    : ctt_hip_msm_bases_create(c->hip, CTT_HIP_BLS12_381_G1, aff.data(), N_BLOB, 0);
-  if (!c->bases) {
-    ctt_hip_msm_ctx_destroy(c->hip);
-    delete c;
-    return TS_InvalidFile;
-  }
+  if (!c->bases) return fail(GPU_UNAVAILABLE);
   c->domain = domain_brp();
-  PROT_HIP_CHECK(hipSetDevice(device));
-  PROT_HIP_CHECK(hipMalloc(&c->d_domain, (size_t)N_BLOB * 32));
-  PROT_HIP_CHECK(hipMalloc(&c->d_poly, (size_t)N_BLOB * 32));
-  PROT_HIP_CHECK(hipMalloc(&c->d_q, (size_t)N_BLOB * 32));
-  PROT_HIP_CHECK(hipMemcpy(c->d_domain, c->domain.data(), (size_t)N_BLOB * 32, hipMemcpyHostToDevice));
+  try {
+    PROT_HIP_CHECK(hipSetDevice(device));
+    PROT_HIP_CHECK(hipMalloc(&c->d_domain, (size_t)N_BLOB * 32));
+    PROT_HIP_CHECK(hipMalloc(&c->d_poly, (size_t)N_BLOB * 32));
+    PROT_HIP_CHECK(hipMalloc(&c->d_q, (size_t)N_BLOB * 32));
+    PROT_HIP_CHECK(hipMemcpy(c->d_domain, c->domain.data(), (size_t)N_BLOB * 32, hipMemcpyHostToDevice));
+  } catch (const HipFailure&) {
+    return fail(GPU_UNAVAILABLE);
+  }
   *out = c;
   return TS_Success;
 }
 
 // [proof]_1 and y = p(z) for a validated polynomial (canonical scalars) and challenge
-void kzg_prove(ctt_eth_kzg_context_struct* c, uint8_t proof[48], uint64_t y_c[4], const uint8_t* poly_le, const uint64_t z_c[4]) {
+// -> KZG_Success, or GPU_UNAVAILABLE when the GPU refused (nothing written)
+int kzg_prove(ctt_eth_kzg_context_struct* c, uint8_t proof[48], uint64_t y_c[4], const uint8_t* poly_le, const uint64_t z_c[4]) {
   std::lock_guard<std::mutex> lock(c->mu);
   PROT_HIP_CHECK(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)ctt_hip_msm_stream(c->hip);
+  if (!s) return GPU_UNAVAILABLE;                       // the context was lost to an earlier HIP failure
   PROT_HIP_CHECK(hipMemcpyAsync(c->d_poly, poly_le, (size_t)N_BLOB * 32, hipMemcpyHostToDevice, s));
   uint8_t r_aff[96];
-  const int rc = ctt_hip_fr_quotient(c->hip, CTT_HIP_BLS12_381_G1, c->d_q, y_c, c->d_poly, c->d_domain, z_c, N_BLOB);
+  uint64_t y_tmp[4];
+  const int rc = ctt_hip_fr_quotient(c->hip, CTT_HIP_BLS12_381_G1, c->d_q, y_tmp, c->d_poly, c->d_domain, z_c, N_BLOB);
   int mrc;
   if (rc == 0) {
     mrc = ctt_hip_msm_with_bases(c->hip, c->bases, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, c->d_q, N_BLOB, 1);
   } else if (rc == -2) {   // z is one of the roots of unity: the reference's other formula, on the host
     std::vector<uint8_t> q((size_t)N_BLOB * 32);
-    quotient_host(c->domain, poly_le, z_c, q.data(), y_c);
+    quotient_host(c->domain, poly_le, z_c, q.data(), y_tmp);
     mrc = ctt_hip_msm_with_bases(c->hip, c->bases, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, q.data(), N_BLOB, 0);
   } else {
-    fprintf(stderr, "[ctt_msm_hip] FATAL: ctt_hip_fr_quotient failed (%d)\n", rc);
-    abort();
+    return GPU_UNAVAILABLE;
   }
-  if (mrc != 0) {
-    fprintf(stderr, "[ctt_msm_hip] FATAL: the proof's MSM was refused (%d)\n", mrc);
-    abort();
-  }
+  if (mrc != 0) return GPU_UNAVAILABLE;
+  memcpy(y_c, y_tmp, 32);
   g1_compress(proof, r_aff);
+  return KZG_Success;
 }
 
 }  // namespace
@@ -583,38 +608,75 @@ void ctt_hip_eth_kzg_quotient_host(uint8_t* q_le, uint8_t y_le[32], const uint8_
 int ctt_hip_eth_kzg_context_from_srs(ctt_eth_kzg_context_struct** ctx, const uint8_t* g1_lagrange_compressed, size_t n_points,
                                      int device, int table) {
   if (!ctx || !g1_lagrange_compressed || n_points != (size_t)N_BLOB) return TS_InvalidFile;
-  return kzg_context_build(ctx, g1_lagrange_compressed, device, table);
+  return gpu_guarded([&]() { return kzg_context_build(ctx, g1_lagrange_compressed, device, table); });
 }
 // The c-kzg text format of the Ethereum ceremony ("4096\n65\n", one hex point per line; the reference ships it as
 // constantine/commitments_setups/trusted_setup_ethereum_kzg4844_reference.dat): format must be cttEthTSFormat_ckzg4844 (0).
+// The reader follows load_ckzg4844 (constantine/commitments_setups/ethereum_kzg_srs.nim:242-350): "%4u" counts, then 4096 Lagrange
+// G1 lines of exactly 96 hex characters, 65 monomial G2 lines of exactly 192, 4096 monomial G1 lines of 96, LF or CRLF line ends;
+// anything else -- a short file, a long line, a character that is not a hex digit -- is cttEthTS_InvalidFile.  The Lagrange points
+// are decompressed and subgroup-checked (they are the commitment key).  The G2 and monomial-G1 sections serve verification and
+// the PeerDAS proofs, which are out of scope here: their lines are checked for length, hex digits, the compression flag and
+// coordinates below p, not decompressed (round 4 did not read them at all: a truncated file loaded -- ADVICE r4).
+static bool srs_hex_line(FILE* f, size_t hex_chars, uint8_t* out) {
+  char buf[200];
+  size_t got = 0;
+  int ch;
+  while ((ch = fgetc(f)) != EOF && ch != '\n' && ch != '\r') {
+    if (got >= hex_chars || !isxdigit(ch)) return false;
+    buf[got++] = (char)ch;
+  }
+  if (got != hex_chars) return false;
+  while (ch == '\r' || ch == '\n') {          // the line end (and blank lines, as fscanf's "%*[\r\n]" skips them)
+    ch = fgetc(f);
+  }
+  if (ch != EOF) ungetc(ch, f);
+  auto nib = [](char c) { return (uint8_t)(c <= '9' ? c - '0' : (c | 0x20) - 'a' + 10); };
+  for (size_t i = 0; i < hex_chars / 2; i++) out[i] = (uint8_t)(nib(buf[2 * i]) << 4 | nib(buf[2 * i + 1]));
+  return true;
+}
+// a compressed point's x coordinate(s): flag bit set, every 48-byte big-endian coordinate below p (the neutral: flags only)
+static bool srs_compressed_shape(const uint8_t* in, int coords) {
+  if (!(in[0] & 0x80)) return false;
+  if (in[0] & 0x40) {
+    if (in[0] & 0x3f) return false;
+    for (int i = 1; i < 48 * coords; i++)
+      if (in[i]) return false;
+    return true;
+  }
+  for (int k = 0; k < coords; k++) {
+    uint8_t be[48];
+    memcpy(be, in + 48 * k, 48);
+    if (k == 0) be[0] &= 0x1f;
+    uint64_t v[FpH::N];
+    limbs_from_be<FpH>(be, v);
+    if (!below_modulus<FpH>(v)) return false;
+  }
+  return true;
+}
 uint8_t ctt_eth_kzg_context_new(ctt_eth_kzg_context_struct** ctx, const char* filepath, uint8_t format) {
   if (!ctx || !filepath || format != 0) return TS_InvalidFile;
   FILE* f = fopen(filepath, "rb");
   if (!f) return TS_MissingOrInaccessibleFile;
   std::vector<uint8_t> srs((size_t)N_BLOB * 48);
-  int n1 = 0, n2 = 0;
+  unsigned n1 = 0, n2 = 0;
   int st = TS_Success;
-  if (fscanf(f, "%d %d", &n1, &n2) != 2 || n1 != N_BLOB || n2 != 65) st = TS_InvalidFile;
+  if (fscanf(f, "%4u\n", &n1) != 1 || n1 != (unsigned)N_BLOB || fscanf(f, "%4u\n", &n2) != 1 || n2 != 65u) st = TS_InvalidFile;
+  for (int i = 0; st == TS_Success && i < N_BLOB; i++)
+    if (!srs_hex_line(f, 96, &srs[(size_t)i * 48])) st = TS_InvalidFile;
+  for (int i = 0; st == TS_Success && i < 65; i++) {
+    uint8_t g2[96];
+    if (!srs_hex_line(f, 192, g2) || !srs_compressed_shape(g2, 2)) st = TS_InvalidFile;
+  }
   for (int i = 0; st == TS_Success && i < N_BLOB; i++) {
-    char tok[128];
-    if (fscanf(f, "%127s", tok) != 1 || strlen(tok) != 96) {
-      st = TS_InvalidFile;
-      break;
-    }
-    for (int b = 0; b < 48; b++) {
-      unsigned v;
-      if (sscanf(tok + 2 * b, "%2x", &v) != 1) {
-        st = TS_InvalidFile;
-        break;
-      }
-      srs[(size_t)i * 48 + b] = (uint8_t)v;
-    }
+    uint8_t g1[48];
+    if (!srs_hex_line(f, 96, g1) || !srs_compressed_shape(g1, 1)) st = TS_InvalidFile;
   }
   fclose(f);
   if (st != TS_Success) return (uint8_t)st;
   const char* dv = getenv("CTT_HIP_DEVICE");
   // the SRS as a window table: 10 MB for 4096 points, commitments 0.38 instead of 0.52 ms (profiles/kzg_timing_r04.txt)
-  return (uint8_t)kzg_context_build(ctx, srs.data(), dv ? atoi(dv) : 0, 1);
+  return gpu_guarded([&]() { return kzg_context_build(ctx, srs.data(), dv ? atoi(dv) : 0, 1); });
 }
 // ethereum_eip4844_kzg.h:232: the reference's constructor with PrecomputedMSM lookup tables (t base groups, b bits per window -- CPU
 // tables for the FK20 proofs of PeerDAS).  The same context as above: the SRS is cached on the GPU as a window table whatever t and b
@@ -624,16 +686,17 @@ uint8_t ctt_eth_kzg_context_new_with_precompute(ctt_eth_kzg_context_struct** ctx
 }
 void ctt_eth_kzg_context_delete(ctt_eth_kzg_context_struct* c) {
   if (!c) return;
-  {
+  (void)gpu_guarded([&]() {
     std::lock_guard<std::mutex> lock(c->mu);
-    PROT_HIP_CHECK(hipSetDevice(c->device));
+    (void)hipSetDevice(c->device);
     ctt_hip_msm_sync(c->hip);
     if (c->bases) ctt_hip_msm_bases_destroy(c->hip, c->bases);
-    if (c->d_domain) PROT_HIP_CHECK(hipFree(c->d_domain));
-    if (c->d_poly) PROT_HIP_CHECK(hipFree(c->d_poly));
-    if (c->d_q) PROT_HIP_CHECK(hipFree(c->d_q));
+    if (c->d_domain) (void)hipFree(c->d_domain);
+    if (c->d_poly) (void)hipFree(c->d_poly);
+    if (c->d_q) (void)hipFree(c->d_q);
     if (c->own_hip) ctt_hip_msm_ctx_destroy(c->hip);
-  }
+    return 0;
+  });
   delete c;
 }
 
@@ -647,10 +710,7 @@ uint8_t ctt_eth_kzg_blob_to_kzg_commitment(const ctt_eth_kzg_context_struct* ctx
   {
     std::lock_guard<std::mutex> lock(c->mu);
     const int rc = ctt_hip_msm_with_bases(c->hip, c->bases, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, poly.data(), N_BLOB, 0);
-    if (rc != 0) {
-      fprintf(stderr, "[ctt_msm_hip] FATAL: the commitment's MSM was refused (%d)\n", rc);
-      abort();
-    }
+    if (rc != 0) return GPU_UNAVAILABLE;     // the GPU refused (ctt_hip_last_error says why); dst untouched
   }
   g1_compress(dst, r_aff);
   return KZG_Success;
@@ -665,7 +725,8 @@ uint8_t ctt_eth_kzg_compute_kzg_proof(const ctt_eth_kzg_context_struct* ctx, uin
   std::vector<uint8_t> poly((size_t)N_BLOB * 32);
   const int st = blob_to_scalars(poly.data(), blob);
   if (st != KZG_Success) return (uint8_t)st;
-  kzg_prove(c, proof, y, poly.data(), z);
+  const uint8_t pst = gpu_guarded([&]() { return kzg_prove(c, proof, y, poly.data(), z); });
+  if (pst != KZG_Success) return pst;
   limbs_to_be<FrH>(y, y_be);
   return KZG_Success;
 }
@@ -680,7 +741,7 @@ uint8_t ctt_eth_kzg_compute_blob_kzg_proof(const ctt_eth_kzg_context_struct* ctx
   {
     std::lock_guard<std::mutex> lock(c->mu);
     uint8_t ok = 0;
-    if (ctt_hip_subgroup_check(c->hip, CTT_HIP_BLS12_381_G1, &ok, aff, 1, 0) != 0) abort();
+    if (ctt_hip_subgroup_check(c->hip, CTT_HIP_BLS12_381_G1, &ok, aff, 1, 0) != 0) return GPU_UNAVAILABLE;
     if (!ok) return KZG_EccPointNotInSubgroup;
   }
   std::vector<uint8_t> poly((size_t)N_BLOB * 32);
@@ -688,8 +749,7 @@ uint8_t ctt_eth_kzg_compute_blob_kzg_proof(const ctt_eth_kzg_context_struct* ctx
   if (st != KZG_Success) return (uint8_t)st;
   uint64_t z[4], y[4];
   fiat_shamir_challenge(z, blob, commitment);
-  kzg_prove(c, proof, y, poly.data(), z);
-  return KZG_Success;
+  return gpu_guarded([&]() { return kzg_prove(c, proof, y, poly.data(), z); });
 }
 
 // the _parallel forms (ethereum_eip4844_kzg_parallel.h:40,61,73): the thread pool is not used, as in the MSM's _parallel symbols
@@ -740,7 +800,7 @@ static int evm_validate_and_msm(int curve, void* r_aff, const void* coefs, const
     }
   std::vector<uint8_t> ok(bad ? bad : 1);
   if (bad < n) {   // the call fails anyway: which status -- a point in front of the first malformed pair outside the subgroup?
-    if (bad > 0 && ctt_hip_subgroup_check(nullptr, curve, ok.data(), pts, bad, 0) != 0) abort();
+    if (bad > 0 && ctt_hip_subgroup_check(nullptr, curve, ok.data(), pts, bad, 0) != 0) return GPU_UNAVAILABLE;
     for (size_t i = 0; i < bad; i++)
       if (!ok[i]) return EVM_PointNotInSubgroup;
     return parse[bad];
@@ -758,17 +818,20 @@ static int evm_validate_and_msm(int curve, void* r_aff, const void* coefs, const
   }
   if (!beside) {
     check_rc = ctt_hip_subgroup_check(nullptr, curve, ok.data(), pts, n, 0);
-    if (check_rc != 0) abort();
+    if (check_rc != 0) return GPU_UNAVAILABLE;
     for (size_t i = 0; i < n; i++)
       if (!ok[i]) return EVM_PointNotInSubgroup;
   }
-  const int rc = ctt_hip_msm_host(curve, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, coefs, pts, n);
-  if (beside) check.join();
-  if (rc != 0) {
-    fprintf(stderr, "[ctt_msm_hip] FATAL: the precompile's MSM was refused (%d)\n", rc);
-    abort();
+  // The MSM.  A refusal because both in-flight slots of the context are held by another thread's device-resident tickets passes:
+  // wait for it (up to ~2 s) instead of failing a consensus call; anything else (no device, out of device memory, a HIP failure)
+  // comes back as GPU_UNAVAILABLE with the thread's last error set -- rounds 1-4 aborted the process here.
+  int rc = ctt_hip_msm_host(curve, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, coefs, pts, n);
+  for (int spin = 0; rc == -1 && ctt_hip_last_error() == ERR_REFUSED && spin < 20000; spin++) {
+    std::this_thread::sleep_for(std::chrono::microseconds(100));
+    rc = ctt_hip_msm_host(curve, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, coefs, pts, n);
   }
-  if (check_rc != 0) abort();
+  if (beside) check.join();
+  if (rc != 0 || check_rc != 0) return GPU_UNAVAILABLE;
   for (size_t i = 0; i < n; i++)
     if (!ok[i]) return EVM_PointNotInSubgroup;
   return EVM_Success;

@@ -36,6 +36,8 @@ def _call(sym, out_len, inputs: bytes, r_len=None) -> bytes:
     r = (ctypes.c_uint8 * out_len)()
     buf = (ctypes.c_uint8 * max(1, len(inputs))).from_buffer_copy(inputs if inputs else b"\0")
     rc = getattr(L, sym)(r, out_len if r_len is None else r_len, buf, len(inputs))
+    if rc == _lib.GPU_UNAVAILABLE:      # CTT_HIP_STATUS_GPU_UNAVAILABLE: outside ctt_evm_status, r untouched
+        raise _lib.GpuUnavailable(sym)
     if rc != 0:
         raise EvmError(CttEVMStatus(rc))
     return bytes(r)

@@ -52,6 +52,8 @@ class KzgError(ValueError):
 
 
 def _check(rc):
+    if rc == _lib.GPU_UNAVAILABLE:      # CTT_HIP_STATUS_GPU_UNAVAILABLE: outside the reference's enum, nothing was written
+        raise _lib.GpuUnavailable("EIP-4844 KZG")
     if rc != 0:
         raise KzgError(cttEthKzgStatus(rc))
 
@@ -72,6 +74,8 @@ class EthereumKZGContext:
         h = ctypes.c_void_p()
         rc = self.L.ctt_hip_eth_kzg_context_from_srs(ctypes.byref(h), _buf(srs_lagrange_g1_compressed), FIELD_ELEMENTS_PER_BLOB,
                                                      int(device), 1 if table else 0)
+        if rc == _lib.GPU_UNAVAILABLE:
+            raise _lib.GpuUnavailable("KZG context")
         if rc != 0:
             raise ValueError(cttEthTrustedSetupStatus(rc).name)
         self.handle = h
@@ -88,6 +92,8 @@ class EthereumKZGContext:
             rc = self.L.ctt_eth_kzg_context_new_with_precompute(ctypes.byref(h), str(path).encode(), 0, int(precompute[0]), int(precompute[1]))
         else:
             rc = self.L.ctt_eth_kzg_context_new(ctypes.byref(h), str(path).encode(), 0)
+        if rc == _lib.GPU_UNAVAILABLE:
+            raise _lib.GpuUnavailable("KZG context")
         if rc != 0:
             raise ValueError(cttEthTrustedSetupStatus(rc).name)
         self.handle = h

@@ -10,8 +10,10 @@
  *   parallel : bindings/c_curve_decls_parallel.nim:33-45    -> include/constantine/curves/{bls12_381,bn254_snarks,pallas,vesta}_parallel.h:20-23
  *
  * All pointers are HOST pointers, buffers are caller-owned, `r` is out-only, the functions block until the
- * result is written, return void and never report an error (same contract as the reference); on a HIP failure
- * the process aborts with a diagnostic -- there is no CPU fallback.  `tp` is accepted and ignored (the GPU
+ * result is written, return void and never report an error (same contract as the reference); there is no CPU
+ * fallback, so a call of these `void` symbols that the GPU cannot serve aborts with a diagnostic.  Every symbol with a
+ * return value -- the neutral spellings of the same MSM (Part 1c), Part 2, and the protocol symbols of Part 3 --
+ * reports a GPU refusal through it instead and never aborts (round 5; ctt_hip_last_error() says why).  `tp` is accepted and ignored (the GPU
  * replaces the thread pool).  len == 0 yields the neutral element (undefined behaviour upstream).
  * The result is the same group element as the reference's; its (X,Y,Z) representative is the canonical one
  * with Z = 1 (neutral: jac (1,1,0), prj (0,1,0)).
@@ -136,8 +138,18 @@ CTT_BATCH_AFFINE_DECL(vesta_ec_prj, vesta_ec_aff)
  * name once.  Same argument meaning as Part 1 (host pointers, caller-owned, r out-only); the difference is the `int` they
  * return, the error channel the Constantine names lack: 0 = r holds the result; -1 = bad id, len above 2^31-1, or both
  * in-flight slots of the default context taken by tickets of Part 2; -2 = out of device memory.  r is untouched on an error
- * and the binding runs the reference's CPU path instead.  ctt_hip_msm_available() never aborts: 1 when a HIP device is
- * present (the probe a binding makes once), else 0. */
+ * and the binding runs the reference's CPU path instead (also -1, never an abort: no usable HIP device, or a HIP runtime call
+ * failed -- ctt_hip_last_error() tells the cases apart).  ctt_hip_msm_available(): 1 when a HIP device is present (the probe
+ * a binding makes once), else 0.
+ *
+ * Why a call was refused -- per thread, set by every symbol of this header that returns an error value (NULL, -1, -2, or Part 3's
+ * CTT_HIP_STATUS_GPU_UNAVAILABLE); a successful call leaves it alone:
+ *    0 none   -1 refused (bad arguments; both in-flight slots of the context taken)   -2 out of device memory
+ *   -3 no usable HIP device   -4 a HIP runtime call failed: the context it happened on is LOST -- every later call on it is
+ *      refused with -4; destroy it and create a new one (the default context of the host-pointer symbols stays lost) */
+int ctt_hip_last_error(void);
+const char* ctt_hip_last_error_message(void);   /* the same, in words; valid until the thread's next refused call */
+void ctt_hip_clear_last_error(void);
 enum { CTT_HIP_BLS12_381_G1 = 0, CTT_HIP_BLS12_381_G2 = 1, CTT_HIP_BN254_SNARKS_G1 = 2,
        CTT_HIP_BN254_SNARKS_G2 = 3, CTT_HIP_PALLAS = 4, CTT_HIP_VESTA = 5 };
 enum { CTT_HIP_COEF_BIG = 0, CTT_HIP_COEF_FR = 1 };
@@ -271,8 +283,12 @@ void* ctt_hip_msm_stream(ctt_hip_msm_ctx* ctx);
  *   include/constantine/protocols/ethereum_evm_precompiles.h:386 (g1msm), :419 (g2msm)
  * (constantine/ethereum_eip4844_kzg.nim:297-444, constantine/ethereum_evm_precompiles.nim:894-1060).  Host side in C++
  * (constantine_amd/csrc/protocols.hip), MSMs / subgroup checks / quotient polynomial on the GPU.  Verification (pairings), the
- * PeerDAS cell functions and the other precompiles are out of scope and not exported.  There is no CPU fallback: a call the
- * GPU cannot serve aborts with a message (these status enums have no member for it). */
+ * PeerDAS cell functions and the other precompiles are out of scope and not exported.  There is no CPU fallback, and none of
+ * these symbols terminates the process (round 5; rounds 1-4 aborted): a call the GPU cannot serve -- no device, out of device
+ * memory, a failed HIP call -- returns CTT_HIP_STATUS_GPU_UNAVAILABLE, a value outside every status enum below (the reference's
+ * *_status_to_string print "InvalidStatusCode" for it), leaves its outputs untouched, and ctt_hip_last_error() of the calling
+ * thread says why.  A precompile whose context is momentarily held by another thread's tickets waits for it (up to ~2 s). */
+#define CTT_HIP_STATUS_GPU_UNAVAILABLE 0xF0
 #ifndef CTT_MSM_HIP_NO_PROTOCOLS
 typedef uint8_t ctt_byte;   /* the reference's `byte` (constantine/core/datatypes.h) */
 typedef struct ctt_eth_kzg_context_struct ctt_eth_kzg_context;

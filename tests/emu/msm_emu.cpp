@@ -65,6 +65,20 @@ struct EmuBackend {
   // the GPU parity tests); plain counting sort per window
   void launch_digits_sort(const SortArgs& a) {
     const uint32_t n = a.n, B = a.B;
+    // the sort clears the empty buckets (SortArgs::zero_base); the others are poisoned here, so that a bucket the accumulation
+    // and the merge fail to write cannot pass for the neutral element
+    if (a.zero_bytes) memset(a.zero_base, 0xA5, (size_t)a.W * B * a.zero_bytes);
+    struct ZeroEmpty {
+      const SortArgs& a;
+      ~ZeroEmpty() {
+        if (!a.zero_bytes) return;
+        for (uint32_t w = 0; w < a.W; w++)
+          for (uint32_t b = 0; b < a.B; b++) {
+            const uint32_t* bs = a.bstart + (size_t)w * (a.B + 1);
+            if (bs[b + 1] == bs[b]) memset((char*)a.zero_base + ((size_t)w * a.B + b) * a.zero_bytes, 0, a.zero_bytes);
+          }
+      }
+    } zero_empty{a};
     std::vector<uint32_t> dg(n), cnt(B);
     *a.maxcount = 0;
     if (a.merged) {
@@ -143,6 +157,26 @@ struct EmuBackend {
     if (merge_chain_bound<F>(a) > 1)
       for (uint32_t w = 0; w < W; w++) for (uint32_t g = 0; g < a.G; g++) merge_final_body<F>(a, w, g);
   }
+  template <class F>
+  void launch_merge_tail_queue(const MergeArgs<F>& a, uint32_t W) {
+    for (uint32_t w = 0; w < W; w++)
+      for (uint32_t g = 0; g < a.G; g++) {
+        uint32_t item = 0;
+        if (merge_tail_queue_body<F>(a, w, g, &item)) {
+          if (*a.qcount >= merge_queue_capacity(W, a.G)) abort();   // the queue's capacity (launch_merge_queue's grid)
+          a.queue[(*a.qcount)++] = item;
+        }
+      }
+  }
+  template <class F>
+  void launch_merge_queue(const MergeArgs<F>& a, uint32_t W, uint32_t lmax) {
+    for (uint32_t qi = 0; qi < merge_queue_capacity(W, a.G); qi++) merge_queue_body<F>(a, qi, lmax);
+  }
+  template <class F>
+  void launch_merge_long(const MergeArgs<F>& a, uint32_t W, uint32_t lmax) {
+    // one "workgroup" of one lane per window (the barrier is a no-op), as for merge_finish_body
+    for (uint32_t w = 0; w < W; w++) merge_long_body<F>(a, w, lmax, 0, 1, []() {});
+  }
   static bool pyr_goes_to_tail(uint32_t, uint32_t) { return false; }
   template <class F>
   void launch_window_groups(const XYZZ<F>* out, XYZZ<F>* wsum, uint32_t W, int c, int h, int ngrp) {
@@ -191,6 +225,8 @@ static void emu_env_options(MsmOptions& o) {
   const char* s;
   if ((s = getenv("EMU_HORNER_BITS"))) o.horner_bits = atoi(s);
   if ((s = getenv("EMU_HOST_WINDOW_SUMS"))) o.host_window_sums = atoi(s);
+  if ((s = getenv("EMU_MERGE_CHAIN"))) o.merge_chain = atoi(s);
+  if ((s = getenv("EMU_MERGE_LMAX"))) o.merge_lmax = atoi(s);
 }
 
 template <class C>

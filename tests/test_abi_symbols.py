@@ -135,3 +135,42 @@ def test_subgroup_check_of_a_few_host_points_runs_on_the_host():
         # the 16-thread split
         many = curve.points_to_array((pts * 5)[:60])
         assert [bool(v) for v in subgroup_check(name, many)] == (want * 5)[:60], name
+
+
+def test_without_a_device_calls_are_refused_not_fatal():
+    """Round 5: no symbol with a return value terminates the process.  On a box without a HIP device -- this
+    container -- the neutral MSM symbol returns -1, the protocol symbols return CTT_HIP_STATUS_GPU_UNAVAILABLE (0xF0, outside the
+    reference's status enums), outputs stay untouched and ctt_hip_last_error() says -3 (no usable device).  Host-only work that
+    comes first still yields the reference's statuses.  (The Constantine-named void MSM symbols have no channel and abort.)"""
+    from constantine_amd import _lib, evm, kzg
+    from oracle import pyoracle as po
+    L = _lib.lib()
+    if L.ctt_hip_msm_available() == 1:
+        pytest.skip("a HIP device is present: the refusal path of a device-less box cannot be shown here")
+    curve = po.CURVES["bls12_381_g1"]
+    G = curve.gen
+    pts = curve.points_to_array([G, G])
+    sc = curve.scalars_to_array([3, 4])
+    r = (ctypes.c_uint8 * 144)(*([0xAB] * 144))
+    L.ctt_hip_clear_last_error()
+    assert L.ctt_hip_last_error() == 0
+    rc = L.ctt_hip_msm_host(0, 0, 1, r, sc.ctypes.data_as(ctypes.c_void_p), pts.ctypes.data_as(ctypes.c_void_p), 2)
+    assert rc == -1 and L.ctt_hip_last_error() == -3 and b"no HIP device" in L.ctt_hip_last_error_message()
+    assert bytes(r) == bytes([0xAB]) * 144                       # r untouched
+    assert L.ctt_hip_msm_ctx_create(0) is None
+    # EIP-2537: a well-formed pair is refused with the sentinel; a malformed input still gets the reference's status first
+    x, y = G
+    pair = x.to_bytes(64, "big") + y.to_bytes(64, "big") + (5).to_bytes(32, "big")
+    with pytest.raises(_lib.GpuUnavailable) as e:
+        evm.eth_evm_bls12381_g1msm(pair)
+    assert e.value.code == -3
+    with pytest.raises(evm.EvmError, match="cttEVM_InvalidInputSize"):
+        evm.eth_evm_bls12381_g1msm(pair[:-1])
+    with pytest.raises(evm.EvmError, match="cttEVM_PointNotOnCurve"):
+        evm.eth_evm_bls12381_g1msm(x.to_bytes(64, "big") + (y + 1).to_bytes(64, "big") + (5).to_bytes(32, "big"))
+    # EIP-4844: the context cannot be built without a device -- reported, not fatal; a malformed SRS is still cttEthTS_InvalidFile
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "kzg4844_srs_g1_lagrange.bin"), "rb").read()
+    with pytest.raises(_lib.GpuUnavailable):
+        kzg.EthereumKZGContext(raw)
+    with pytest.raises(ValueError, match="cttEthTS_InvalidFile"):
+        kzg.EthereumKZGContext(bytes(48) + raw[48:])             # an all-zero line: no compression flag

@@ -277,6 +277,42 @@ def test_head_chains_of_every_length_class():
             assert bytes(out) == bytes(expect), (n_equal, c)
 
 
+def test_head_merge_chain_form_and_tree_agree(monkeypatch):
+    """Round 5: the head merge has a chain form (one lane adds up the heads of its bucket; chains above `lmax` heads go to the
+    one-workgroup tree, merge_long_body) next to the launch-per-level tree.  Both forms, every lmax class (every chain long,
+    some long, none long), on inputs whose chains hold 1 ... 250 heads, a quarter-equal and an all-equal input, G1 and G2."""
+    K = 4
+    rng = np.random.default_rng(11)
+    cases = []
+    name = "bn254_snarks_g1"
+    for n_equal in (0, 9, 40, 258):
+        n = n_equal + 200
+        pts = cref.gen_points(name, 1700 + n_equal, n)
+        sc = cref.synth_scalars(1701 + n_equal, n, 254)
+        if n_equal:
+            idx = rng.permutation(n)[:n_equal]
+            sc[idx] = sc[idx[0]]
+        cases.append((name, sc, pts))
+    pts = cref.gen_points(name, 1801, 300)
+    cases.append((name, np.tile(cref.synth_scalars(1802, 1, 254), (300, 1)), pts))     # all equal: one chain per window
+    g2 = "bls12_381_g2"
+    pts2 = cref.gen_points(g2, 1901, 90)
+    sc2 = cref.synth_scalars(1902, 90, 255)
+    sc2[:40] = sc2[0]
+    cases.append((g2, sc2, pts2))
+    for cname, sc, pts in cases:
+        expect, _ = cref.msm(cname, sc, pts)
+        for mode, lmax in ((2, 0), (1, 1), (1, 2), (1, 3), (1, 8), (1, 1000), (0, 0)):
+            monkeypatch.setenv("EMU_MERGE_CHAIN", str(mode))
+            monkeypatch.setenv("EMU_MERGE_LMAX", str(lmax))
+            for c in (5, 9):
+                out, _ = emu.msm(cname, sc, pts, c=c, K=K)
+                assert bytes(out) == bytes(expect), (cname, len(sc), mode, lmax, c)
+            # the host-pointer form merges once per slice, the later slices into the stored sums
+            out, _ = emu.msm_host(cname, sc, pts, chunks=3)
+            assert bytes(out) == bytes(expect), (cname, len(sc), mode, lmax, "slices")
+
+
 @pytest.mark.parametrize("name", ALL)
 def test_window_table_for_cached_bases(name):
     """MsmEngine::prepare_table + the window-table plan: T[w][j] = 2^(c*w) * P_j, every digit window selects a table row,

@@ -112,3 +112,104 @@ def test_subgroup_check_kernel_rejects_points_outside_the_subgroup(name):
     reps = 400 // len(distinct) + 1                               # > 256 points: the launch, not the host path
     got = subgroup_check(name, curve.points_to_array(distinct * reps))
     assert [bool(v) for v in got] == want * reps
+
+
+@pytest.mark.gpu
+def test_points_of_small_order_go_through_the_msm_and_are_rejected():
+    """up to 256 pairs the MSM is issued while the subgroup checks still run on host threads, so curve points OUTSIDE the
+    subgroup -- of order 3, of order 11, of full cofactor order -- reach the sort and the accumulation with scalars reduced mod r
+    before the call is rejected.  The kernels must take any curve point (their additions handle P = +-Q and the neutral; nothing
+    assumes the order), and the status must be cttEVM_PointNotInSubgroup whatever position the point has."""
+    from constantine_amd import evm
+    from oracle import pyoracle as po
+    curve = po.BLS12_381_G1
+    p, r = curve.F.p, curve.order
+    h = 0x396c8c005555e1568c00aaab0000aaab                    # cofactor of E(Fp) (config_fields_and_curves.nim:269-287) = 3 * 11^2 * ...
+    assert h % 3 == 0 and h % 121 == 0
+    off = []
+    x = 1
+    while len(off) < 3:
+        x += 1
+        y2 = (x * x * x + 4) % p
+        y = pow(y2, (p + 1) // 4, p)
+        if y * y % p != y2:
+            continue
+        P = (x, y)
+        if curve.scalar_mul(r, P) is None:
+            continue                                           # (in the subgroup by accident)
+        off.append(P)
+    small = []
+    for P in off:
+        Q = curve.scalar_mul(h // 3 * r, P)                    # the 3-part of E(Fp) is Z/3
+        if Q is not None:
+            assert curve.scalar_mul(3, Q) is None
+            small.append((3, Q))
+        Q = curve.scalar_mul(h // 121 * r, P)                  # the 11-part has order 121: Z/121 or Z/11 x Z/11
+        if Q is not None and curve.scalar_mul(11, Q) is not None:
+            Q = curve.scalar_mul(11, Q)
+        if Q is not None:
+            assert curve.scalar_mul(11, Q) is None             # order exactly 11
+            small.append((11, Q))
+    assert {q for q, _ in small} == {3, 11}
+
+    def enc(P, k):
+        return P[0].to_bytes(64, "big") + P[1].to_bytes(64, "big") + k.to_bytes(32, "big")
+    G = curve.gen
+    bad_points = [Q for _, Q in small] + off
+    for Q in bad_points:
+        for k in (1, 2, 3, r - 1, 2**256 - 1):
+            with pytest.raises(evm.EvmError) as e:
+                evm.eth_evm_bls12381_g1msm(enc(Q, k))
+            assert e.value.status == evm.CttEVMStatus.cttEVM_PointNotInSubgroup
+    # among valid pairs, at the front, in the middle and at the end of calls that take the "MSM beside the checks" path (<= 256
+    # pairs) and of one that checks first (> 256); many copies of an order-3 point (P = +-Q additions inside one bucket)
+    for n, where in ((16, 0), (100, 57), (256, 255), (300, 299)):
+        pairs = [enc(curve.scalar_mul(i + 2, G), 0x1234567 * (i + 1)) for i in range(8)]
+        body = [pairs[i % 8] for i in range(n)]
+        body[where] = enc(small[0][1], 7)
+        with pytest.raises(evm.EvmError) as e:
+            evm.eth_evm_bls12381_g1msm(b"".join(body))
+        assert e.value.status == evm.CttEVMStatus.cttEVM_PointNotInSubgroup, (n, where)
+    body = [enc(small[0][1], i + 1) for i in range(64)]
+    with pytest.raises(evm.EvmError) as e:
+        evm.eth_evm_bls12381_g1msm(b"".join(body))
+    assert e.value.status == evm.CttEVMStatus.cttEVM_PointNotInSubgroup
+    # and the engine is still fine afterwards
+    out = evm.eth_evm_bls12381_g1msm(enc(G, 5) + enc(G, 6))
+    Q = curve.scalar_mul(11, G)
+    assert out == Q[0].to_bytes(64, "big") + Q[1].to_bytes(64, "big")
+
+
+@pytest.mark.gpu
+def test_precompile_calls_from_several_threads():
+    """Callers on several threads no longer take turns on one default context: a second context on the same device is opened when
+    the first is busy ($CTT_HIP_HOST_CONTEXTS).  Four threads, mixed call sizes, every result the single-threaded one."""
+    import threading
+    from constantine_amd import evm
+    from oracle import pyoracle as po
+    curve = po.BLS12_381_G1
+    G = curve.gen
+
+    def enc(P, k):
+        return P[0].to_bytes(64, "big") + P[1].to_bytes(64, "big") + k.to_bytes(32, "big")
+    pts = [curve.scalar_mul(i + 2, G) for i in range(8)]
+    jobs = []
+    for n in (1, 7, 64, 300):
+        ks = [0x9E3779B97F4A7C15 * (i + 1) % curve.order for i in range(n)]
+        want = curve.scalar_mul(sum(k * (i % 8 + 2) for i, k in enumerate(ks)) % curve.order, G)
+        jobs.append((b"".join(enc(pts[i % 8], k) for i, k in enumerate(ks)), want[0].to_bytes(64, "big") + want[1].to_bytes(64, "big")))
+    errors = []
+
+    def work():
+        try:
+            for _ in range(5):
+                for inp, want in jobs:
+                    assert evm.eth_evm_bls12381_g1msm(inp) == want
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+    ths = [threading.Thread(target=work) for _ in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors

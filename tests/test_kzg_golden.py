@@ -215,8 +215,13 @@ def test_kzg_context_from_the_ceremony_text_file(tmp_path):
     from constantine_amd import kzg
     raw = open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read()
     path = tmp_path / "setup.txt"
-    g2 = bytes([0xC0]) + bytes(95)   # the 65 G2 lines are not read by the commitment / proof functions
-    path.write_text("4096\n65\n" + "\n".join(raw[48 * i:48 * i + 48].hex() for i in range(4096)) + "\n" + "\n".join([g2.hex()] * 65) + "\n")
+    # the G2 and monomial-G1 sections are not used by the commitment / proof functions, but the loader reads them like the
+    # reference's (load_ckzg4844): length, hex digits, compression flag, coordinates below p.  The golden fixture holds the Lagrange
+    # section only: the neutral element stands in for the 65 G2 points, the Lagrange lines for the 4096 monomial ones
+    g2 = bytes([0xC0]) + bytes(95)
+    g1_lines = [raw[48 * i:48 * i + 48].hex() for i in range(4096)]
+    text = "4096\n65\n" + "\n".join(g1_lines) + "\n" + "\n".join([g2.hex()] * 65) + "\n" + "\n".join(g1_lines) + "\n"
+    path.write_text(text)
     ctx = kzg.EthereumKZGContext.from_ckzg_text(path)
     try:
         name, blob, com = next(c for c in _golden.kzg4844_raw_cases() if c[2] is not None)
@@ -230,10 +235,63 @@ def test_kzg_context_from_the_ceremony_text_file(tmp_path):
         ctx.delete()
     with pytest.raises(ValueError, match="cttEthTS_MissingOrInaccessibleFile"):
         kzg.EthereumKZGContext.from_ckzg_text(tmp_path / "nope.txt")
+    # what load_ckzg4844 rejects: a character that is not a hex digit (sscanf's "%2x" took "+f" in round 4), a short or a long line, a
+    # file that ends before its G2 or monomial section, counts other than 4096 / 65; CRLF line ends are fine
     bad = tmp_path / "bad.txt"
-    bad.write_text("4096\n65\n" + raw[:48].hex() + "\nzz\n")
-    with pytest.raises(ValueError, match="cttEthTS_InvalidFile"):
-        kzg.EthereumKZGContext.from_ckzg_text(bad)
+    cases = {
+        "non-hex": text.replace(g1_lines[7], "+f" + g1_lines[7][2:], 1),
+        "short line": text.replace(g1_lines[9], g1_lines[9][:-2], 1),
+        "long line": text.replace(g1_lines[9], g1_lines[9] + "00", 1),
+        "no monomial section": "4096\n65\n" + "\n".join(g1_lines) + "\n" + "\n".join([g2.hex()] * 65) + "\n",
+        "truncated G2 section": "4096\n65\n" + "\n".join(g1_lines) + "\n" + "\n".join([g2.hex()] * 10) + "\n",
+        "G2 without the compression flag": text.replace(g2.hex(), "00" * 96, 1),
+        "wrong count": text.replace("4096\n65\n", "4095\n65\n", 1),
+        "zz": "4096\n65\n" + raw[:48].hex() + "\nzz\n",
+    }
+    for what, body in cases.items():
+        bad.write_text(body)
+        with pytest.raises(ValueError, match="cttEthTS_InvalidFile"):
+            kzg.EthereumKZGContext.from_ckzg_text(bad)
+            raise AssertionError(what + " was accepted")
+    crlf = tmp_path / "crlf.txt"
+    crlf.write_bytes(text.replace("\n", "\r\n").encode())
+    ctx = kzg.EthereumKZGContext.from_ckzg_text(crlf)
+    try:
+        assert kzg.blob_to_kzg_commitment(ctx, blob) == com
+    finally:
+        ctx.delete()
+
+
+@pytest.mark.gpu
+def test_two_kzg_contexts_on_two_threads():
+    """Two contexts, each with its own streams and lock, used from two threads at once (no process-wide lock on the path):
+    every commitment and proof equals the single-threaded answer."""
+    import threading
+    from constantine_amd import kzg
+    raw = open(os.path.join(_golden.HERE, "kzg4844_srs_g1_lagrange.bin"), "rb").read()
+    blobs = [(blob, com) for _, blob, com in _golden.kzg4844_raw_cases() if com is not None][:4]
+    ctxs = [kzg.EthereumKZGContext(raw), kzg.EthereumKZGContext(raw, table=False)]
+    errors = []
+
+    def work(ctx):
+        try:
+            for _ in range(6):
+                for blob, com in blobs:
+                    assert kzg.blob_to_kzg_commitment(ctx, blob) == com
+                    proof = kzg.compute_blob_kzg_proof(ctx, blob, com)
+                    assert len(proof) == 48
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+    try:
+        ths = [threading.Thread(target=work, args=(c,)) for c in ctxs for _ in range(2)]   # two threads per context, two contexts
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errors, errors
+    finally:
+        for c in ctxs:
+            c.delete()
 
 
 def test_quotient_polynomial_bodies_match_the_host_formula():

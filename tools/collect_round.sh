@@ -46,17 +46,22 @@ python tools/kernel_timeline.py "$DB" 2 > "$OUT/rocprof_${TAG}_kernel_stats.txt"
 
 # SQ counters of the accumulate kernel (own passes, kernel-trace only) for the headline and the 254/255-bit fields,
 # and the kernel statistics of those configs
-sq() {  # tag, mixed adds per launch, bench args...
-  local tag=$1 madds=$2; shift 2
+sq() {  # tag, bench args...   (mixed additions per launch = windows x pairs of the plan the run itself reports)
+  local tag=$1; shift 1
   ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
-      --kernel-trace --output-format csv -d "$OUT/sq1_$tag" -o p -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-latency "$@" > /dev/null 2> "$OUT/sq1_$tag.log" )
+      --kernel-trace --output-format csv -d "$OUT/sq1_$tag" -o p -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-latency "$@" > "$OUT/sq1_$tag.json" 2> "$OUT/sq1_$tag.log" )
   ( cd /tmp && timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/sq2_$tag" -o p -- \
       python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-latency "$@" > /dev/null 2> "$OUT/sq2_$tag.log" )
-  { echo "# SQ / GRBM counters of k_accum, bench.py $*, rocprofv3 --pmc (two passes, --kernel-trace only)"; python tools/sq_summary.py k_accum $madds "$OUT/sq1_$tag" "$OUT/sq2_$tag"; } > "$OUT/pmc_${TAG}_sq_counters_k_accum_$tag.txt" 2>> "$OUT/prof.log"
+  local madds=$(python -c "import json,sys; d=[json.loads(l) for l in open('$OUT/sq1_$tag.json') if l.startswith('{')][-1]['config']; print(d['windows']*d['pairs_per_gpu'])")
+  { echo "# SQ / GRBM counters of k_accum, bench.py $*, rocprofv3 --pmc (two passes, --kernel-trace only); $madds mixed additions per launch (windows x pairs of the run's plan)"; python tools/sq_summary.py k_accum $madds "$OUT/sq1_$tag" "$OUT/sq2_$tag"; } > "$OUT/pmc_${TAG}_sq_counters_k_accum_$tag.txt" 2>> "$OUT/prof.log"
+  rm -rf "$OUT/sq1_$tag" "$OUT/sq2_$tag"
 }
-sq bls12_381_g1_2pow20 16777216
-sq bn254_snarks_g1_2pow22 67108864 --curve bn254_snarks_g1 --log2n 22
-sq pallas_2pow20 16777216 --curve pallas
+sq bls12_381_g1_2pow20
+sq bn254_snarks_g1_2pow22 --curve bn254_snarks_g1 --log2n 22
+sq pallas_2pow20 --curve pallas
+sq bls12_381_g2_2pow20 --curve bls12_381_g2
+sq bls12_381_g1_2pow16 --log2n 16
+sq bls12_381_g1_2pow24 --log2n 24
 for cfg in "bn254_snarks_g1 22" "pallas 20" "bls12_381_g2 20" "bls12_381_g1 16" "bls12_381_g1 18"; do
   set -- $cfg
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_$1" -o p -- python "$REPO/bench.py" --curve $1 --log2n $2 --steps 10 --warmup 2 \

@@ -66,6 +66,12 @@ def main():
             "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
             "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
         ]
+    # what the figures were measured on: bench.py refuses them for any other kernel sources (it computes the same digest)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_sources_digest
+    import time
+    doc["_sources_sha256"] = kernel_sources_digest()
+    doc["_collected"] = time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime())
     json.dump(doc, open(out_json, "w"), indent=1)
     print(open(out_txt).read())
 

@@ -42,8 +42,11 @@ def main():
         print(f"#   VALU wave-instructions per launch {v['SQ_INSTS_VALU']:.4g} = {v['SQ_INSTS_VALU'] * 64 / madds:.0f} per mixed addition (one lane)")
     if "SQ_INSTS_SALU" in v and madds > 0:
         print(f"#   SALU wave-instructions per launch {v['SQ_INSTS_SALU']:.4g} = {v['SQ_INSTS_SALU'] * 64 / madds:.0f} per mixed addition")
-    if "SQ_BUSY_CYCLES" in v and "SQ_INSTS_VALU" in v:
-        pass
+    if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
+        # SQ_ACTIVE_INST_VALU counts, per SIMD, the cycles (in units of four) in which a VALU instruction is executing; the chip has
+        # 8 XCDs x 32 CUs x 4 SIMDs, GRBM_GUI_ACTIVE is summed over the XCDs
+        simd_quad_cycles = v["GRBM_GUI_ACTIVE"] / 8 * 1024 / 4
+        print(f"#   VALU busy: SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs / 4) = {100 * v['SQ_ACTIVE_INST_VALU'] / simd_quad_cycles:.1f} % of the SIMD cycles")
     if "GRBM_GUI_ACTIVE" in v and dur:
         print(f"#   effective clock under the profiler: GRBM_GUI_ACTIVE / 8 XCDs / duration = {v['GRBM_GUI_ACTIVE'] / 8 / (sum(dur) / len(dur)) / 1e3:.2f} GHz")
 
