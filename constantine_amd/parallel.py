@@ -45,7 +45,11 @@ class ShardExchange:
             dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
             nb = self.info.aff_bytes
             self.mine = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(2)]
-            self.all = [[torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.world)] for _ in range(2)]
+            # ONE flat receive buffer per set (all_gather_into_tensor): finish() brings the world_size partials to the host with a
+            # single copy -- a list of per-rank tensors cost one device-to-host copy (and its synchronisation, ~15 us) PER RANK, 0.1 ms of
+            # an 8-GPU step whose MSM is 0.65 ms (2^20 pairs in total: 2^17 per GPU)
+            self.flat = [torch.empty(nb * self.world, dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.into_tensor = hasattr(dist, "all_gather_into_tensor")
 
     def start(self, part):
         import torch
@@ -56,7 +60,15 @@ class ShardExchange:
         k = self.slot
         self.slot ^= 1
         self.mine[k].copy_(torch.from_numpy(part))
-        work = self.dist.all_gather(self.all[k], self.mine[k], group=self.group, async_op=True)
+        work = None
+        if self.into_tensor:
+            try:
+                work = self.dist.all_gather_into_tensor(self.flat[k], self.mine[k], group=self.group, async_op=True)
+            except (RuntimeError, NotImplementedError):
+                self.into_tensor = False      # (a backend without the flat form: the list form below, same bytes)
+        if work is None:
+            views = list(self.flat[k].view(self.world, -1).unbind(0))
+            work = self.dist.all_gather(views, self.mine[k], group=self.group, async_op=True)
         return (work, k)
 
     def finish(self, handle, coord="aff"):
@@ -64,7 +76,7 @@ class ShardExchange:
         if work is None:
             return ec_sum_affine(self.curve, k[None, :], coord=coord)
         work.wait()
-        allp = np.stack([g.cpu().numpy() for g in self.all[k]])
+        allp = self.flat[k].cpu().numpy().reshape(self.world, self.info.aff_bytes)
         return ec_sum_affine(self.curve, allp, coord=coord)
 
 

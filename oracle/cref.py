@@ -47,6 +47,9 @@ def lib(path=None):
         L.oracle_gen_points.argtypes = [i32, u64, sz, sz, vp, i32]
         L.oracle_scalar_mul.argtypes = [i32, vp, vp, vp]
         L.oracle_best_bucket_bit_size.argtypes = [sz, i32]
+        L.oracle_gen_points_unknown_log.argtypes = [i32, u64, sz, sz, vp, i32]
+        L.oracle_psi_g2.argtypes = [i32, vp, vp]
+        L.oracle_decompose_g2.argtypes = [i32, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -94,6 +97,32 @@ def scalar_mul(curve: str, k: np.ndarray, p: np.ndarray) -> np.ndarray:
     out = np.zeros(AFF_BYTES[curve], dtype=np.uint8)
     lib().oracle_scalar_mul(CURVE_ID[curve], _ptr(k), _ptr(p), _ptr(out))
     return out
+
+
+def gen_points_unknown_log(curve: str, seed: int, n: int, first: int = 0, nthreads: int = 0) -> np.ndarray:
+    """Random points of the prime-order subgroup with UNKNOWN discrete logarithms (random x, square root, cofactor clearing: the
+    reference's bench inputs, msm_ref.cpp gen_points_unknown_log); bls12_381_g1 and bn254_snarks_g1."""
+    out = np.zeros((n, AFF_BYTES[curve]), dtype=np.uint8)
+    nt = nthreads or (os.cpu_count() or 1)
+    assert lib().oracle_gen_points_unknown_log(CURVE_ID[curve], seed & (2**64 - 1), first, n, _ptr(out), nt) == 0
+    return out
+
+
+def psi_g2(curve: str, p: np.ndarray) -> np.ndarray:
+    """psi(P) of the M = 4 endomorphism pre-split on G2 (msm_ref.cpp psi)"""
+    p = np.ascontiguousarray(p, dtype=np.uint8)
+    out = np.zeros(AFF_BYTES[curve], dtype=np.uint8)
+    assert lib().oracle_psi_g2(CURVE_ID[curve], _ptr(p), _ptr(out)) == 0
+    return out
+
+
+def decompose_g2(curve: str, k: int):
+    """-> ([m0, m1, m2, m3], [neg0..neg3]): the port's M = 4 decomposition of the scalar k (decomposeEndo, split_scalars.nim:37-123)"""
+    kb = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
+    mini = np.zeros(4 * 32, dtype=np.uint8)
+    neg = (ctypes.c_int * 4)()
+    assert lib().oracle_decompose_g2(CURVE_ID[curve], _ptr(kb), _ptr(mini), neg) == 0
+    return [int.from_bytes(bytes(mini[32 * j:32 * j + 32]), "little") for j in range(4)], [bool(neg[j]) for j in range(4)]
 
 
 def synth_scalars(seed: int, n: int, bits: int, first: int = 0) -> np.ndarray:

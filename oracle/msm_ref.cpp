@@ -34,8 +34,16 @@
 //                                                      phi(x, y) = (beta x, y), named/zoo_endomorphisms.nim:79-92.  BLS12-381, BN254-Snarks, Pallas,
 //                                                      Vesta G1 (M = 2: N -> 2N points, mini-scalars of ceil(bits/2) + 1 bits).
 //
-// Deliberate simplifications (documented in DESIGN.md): the G2 pre-split (M = 4, Frobenius psi) is not restated, and the field
-// inversion is a^(p-2), not the reference's division steps.  Both only change the operation count, never the group element returned.
+//   endomorphism pre-split on G2 (round 5) .......... the same applyEndomorphism with M = 4 (ec_multi_scalar_mul.nim:398-432: `elif ECaff.F is Fp2: 4`):
+//                                                      k -> 4 mini-scalars of ceil(bits/4) + 1 = 65 bits over (P, psi P, psi^2 P, psi^3 P), the
+//                                                      untwist-Frobenius-twist psi(x, y) = (conj(x) c2, conj(y) c3) (computeEndomorphisms,
+//                                                      named/zoo_endomorphisms.nim:94-104), 4 x 4 lattices and Babai vectors of
+//                                                      named/constants/{bls12_381,bn254_snarks}_endomorphisms.nim:39-60 / :39-64; same dispatch as G1.
+//                                                      This is the configuration of the reference's regression test for issue #366 (BN254 G2,
+//                                                      N = 22529: c = 13 divides the 65-bit mini-scalars).
+//
+// Deliberate simplification (documented in DESIGN.md): the field inversion is a^(p-2), not the reference's division steps.  It only
+// changes the operation count, never the group element returned.
 //
 // Build: g++ -O3 -march=native -shared -fPIC -pthread oracle/msm_ref.cpp -o oracle/libmsm_ref.so
 
@@ -242,6 +250,9 @@ struct Fp2 {
     return {F::mul(a.c0, n), F::neg(F::mul(a.c1, n))};
   }
 };
+
+template <class T> struct IsFp2 { static constexpr bool value = false; };
+template <class F> struct IsFp2<Fp2<F>> { static constexpr bool value = true; };
 
 // ------------------------------------------------------------------------------------------
 // Curves
@@ -669,6 +680,71 @@ static void apply_endomorphism(const EndoG1& E, const F& beta, const Scalar* coe
 template <class F> struct EndoFor { static const EndoG1* get(int) { return nullptr; } static F beta(int) { return F::zero(); } };
 
 // ------------------------------------------------------------------------------------------
+// Endomorphism pre-split on G2 (M = 4): psi = twist^-1 o Frobenius o twist acts on the order-r subgroup as [p mod r]
+// ------------------------------------------------------------------------------------------
+struct EndoG2 {
+  u64 babai[4][4];      // <= 193 bits
+  bool babai_neg[4];
+  u64 lat[4][4];        // lattice[basis][miniscalar]: <= 64 bits
+  bool lat_neg[4][4];
+};
+// decomposeEndo with M = 4 (split_scalars.nim:37-123): alphas[i] = high words of babai[i] * k (w = 4 words),
+// k_j = [j == 0] k -+ sum_i alpha_i b_ij; a negative mini-scalar is negated and its point with it
+static void decompose_endo4(const EndoG2& E, const Scalar& k, Scalar mini[4], bool neg[4]) {
+  U256 alpha[4];
+  for (int i = 0; i < 4; i++) alpha[i] = mul_limbs(E.babai[i], 4, k.l, 4, 4);   // (babai_i * k) >> 256
+  U256 kk[4] = {u256_from(k.l, 4), U256{{0, 0, 0, 0}}, U256{{0, 0, 0, 0}}, U256{{0, 0, 0, 0}}};
+  for (int j = 0; j < 4; j++)
+    for (int i = 0; i < 4; i++) {
+      if (E.lat[i][j] == 0) continue;
+      const U256 ab = mul_limbs(alpha[i].l, 4, &E.lat[i][j], 1, 0);
+      if (E.lat_neg[i][j] != E.babai_neg[i]) kk[j] = u256_add(kk[j], ab); else kk[j] = u256_sub(kk[j], ab);
+    }
+  for (int j = 0; j < 4; j++) {
+    neg[j] = (kk[j].l[3] >> 63) != 0;
+    if (neg[j]) kk[j] = u256_neg(kk[j]);
+    memcpy(mini[j].l, kk[j].l, sizeof(mini[j].l));
+  }
+}
+template <class F2>
+struct PsiCoef { F2 c2, c3; };
+template <class F2>
+static F2 fp2_pow(F2 a, const u64* e, int nl) {
+  F2 r = F2::one();
+  for (int i = nl * 64 - 1; i >= 0; i--) {
+    r = F2::sqr(r);
+    if ((e[i / 64] >> (i % 64)) & 1) r = F2::mul(r, a);
+  }
+  return r;
+}
+// frobenius_psi (constantine/math/pairings... named/zoo_endomorphisms.nim:94-104 -> extension_fields frobenius): (x, y) -> (conj(x) c2, conj(y) c3)
+template <class F2>
+static Aff<F2> psi(const PsiCoef<F2>& C, const Aff<F2>& p) {
+  if (p.is_inf()) return p;
+  F2 cx{p.x.c0, decltype(p.x.c0)::neg(p.x.c1)}, cy{p.y.c0, decltype(p.y.c0)::neg(p.y.c1)};
+  return {F2::mul(cx, C.c2), F2::mul(cy, C.c3)};
+}
+// applyEndomorphism with M = 4 (ec_multi_scalar_mul.nim:398-432): (k_i, P_i) -> (k_ij, +-psi^j P_i), j = 0..3, interleaved as there
+template <class F2>
+static void apply_endomorphism4(const EndoG2& E, const PsiCoef<F2>& C, const Scalar* coefs, const Aff<F2>* pts, size_t n,
+                                std::vector<Scalar>& ec, std::vector<Aff<F2>>& ep) {
+  ec.resize(4 * n);
+  ep.resize(4 * n);
+  for (size_t i = 0; i < n; i++) {
+    bool neg[4];
+    decompose_endo4(E, coefs[i], &ec[4 * i], neg);
+    Aff<F2> q = pts[i];
+    for (int j = 0; j < 4; j++) {
+      if (j) q = psi<F2>(C, q);
+      Aff<F2> t = q;
+      if (neg[j]) t.y = F2::neg(t.y);     // the neutral (0,0) stays (0,0)
+      ep[4 * i + j] = t;
+    }
+  }
+}
+template <class F> struct EndoG2For { static const EndoG2* get(int) { return nullptr; } static const PsiCoef<F>& psi_coef(int) { static const PsiCoef<F> z{}; return z; } };
+
+// ------------------------------------------------------------------------------------------
 // Curve table
 // ------------------------------------------------------------------------------------------
 
@@ -732,6 +808,19 @@ static int do_msm(int curve, const void* scalars, const void* points, size_t n, 
     if (c > 16) c = 16;
   }
   Jac<F> r;
+  if constexpr (IsFp2<F>::value) {
+    const bool endo2 = c_override <= 0 && EndoG2For<F>::get(curve) != nullptr &&
+                       endo_applies(best_bucket_bit_size(n, bits, true, true), bits, nthreads);
+    if (endo2) {
+      std::vector<Scalar> ec;
+      std::vector<Aff<F>> ep;
+      apply_endomorphism4<F>(*EndoG2For<F>::get(curve), EndoG2For<F>::psi_coef(curve), k, p, n, ec, ep);
+      const int L = (bits + 3) / 4 + 1;   // computeEndoRecodedLength(bits, 4) (split_scalars.nim:315-316): 65
+      r = nthreads > 1 ? msm_parallel<F>(ec.data(), ep.data(), 4 * n, L, c, nthreads) : msm_serial<F>(ec.data(), ep.data(), 4 * n, L, c);
+      *o = r.to_aff();
+      return c;
+    }
+  }
   if (endo) {
     std::vector<Scalar> ec;
     std::vector<Aff<F>> ep;
@@ -799,6 +888,65 @@ static void gen_points(const Aff<F>& G, u64 seed, size_t first, size_t n, void* 
 
 template <class F> static Aff<F> aff_from_u64(u64 x, u64 y) { return {F::from_u64(x), F::from_u64(y)}; }
 
+// Random curve points with UNKNOWN discrete logarithms, the way the reference's benches make their inputs
+// (helpers/prng_unsafe.nim:306-316 random_unsafe(ECP) -> trySetFromCoordX; benchmarks/bench_elliptic_parallel_template.nim:78-102 then
+// clears the cofactor): x from a 2x-width uniform integer reduced mod p, accepted when x^3 + b is a square, y = the root
+// (x^3 + b)^((p+1)/4) (p = 3 mod 4 for BLS12-381 and BN254-Snarks), then [h] (x, y).  The stream is this file's splitmix64, not the
+// reference's xoshiro: what matters to the tests built on it is that nobody knows log_G of these points -- the synthetic inputs
+// [s_i]G of gen_points let a test compute the MSM as one scalar multiplication; these do not.
+template <class F>
+static void gen_points_unknown_log(u64 b_small, const u64* cofactor, int cof_limbs, u64 seed, size_t first, size_t n, void* out, int nthreads) {
+  Aff<F>* o = (Aff<F>*)out;
+  constexpr int N = F::N;
+  // (p + 1) / 4
+  u64 e[N];
+  {
+    u64 one[N] = {1}, t[N];
+    add_n<N>(t, F::ctx.p, one);       // p + 1 does not overflow: the moduli have spare bits
+    for (int i = 0; i < N; i++) e[i] = (t[i] >> 2) | (i + 1 < N ? t[i + 1] << 62 : 0);
+  }
+  const F b = F::from_u64(b_small);
+  // R mod p as a field element times x_hi gives the 2x-width reduction: x = (hi * 2^(64 N) + lo) mod p
+  auto work = [&](size_t lo_i, size_t hi_i) {
+    for (size_t i = lo_i; i < hi_i; i++) {
+      for (u64 attempt = 0;; attempt++) {
+        u64 w[2 * N];
+        for (int q = 0; q < 2 * N; q++) w[q] = splitmix64(seed * 0x9E3779B97F4A7C15ull + (first + i) * 64 + attempt * 2 * N + q);
+        // reduce: to_mont(lo) and to_mont(hi) are lo R and hi R; x R = lo R + (hi R)(R R)/R ... = lo R + mont_mul(hi R, R^2 R / R)
+        F xl, xh;
+        for (int q = 0; q < N; q++) { xl.l[q] = w[q]; xh.l[q] = w[N + q]; }
+        while (geq_n<N>(xl.l, F::ctx.p)) sub_n<N>(xl.l, xl.l, F::ctx.p);
+        while (geq_n<N>(xh.l, F::ctx.p)) sub_n<N>(xh.l, xh.l, F::ctx.p);
+        const F X = F::add(F::to_mont(xl), F::mul(F::to_mont(xh), F::to_mont(F::one())));   // lo + hi * 2^(64 N)  (mod p)
+        const F rhs = F::add(F::mul(F::sqr(X), X), b);
+        F y = F::one();
+        for (int bit = 64 * N - 1; bit >= 0; bit--) {
+          y = F::sqr(y);
+          if ((e[bit / 64] >> (bit % 64)) & 1) y = F::mul(y, rhs);
+        }
+        if (!(F::sqr(y) == rhs)) continue;          // not a square: next candidate
+        const Aff<F> P{X, y};
+        Jac<F> r = Jac<F>::inf();
+        for (int bit = 64 * cof_limbs - 1; bit >= 0; bit--) {
+          r = Jac<F>::dbl(r);
+          if ((cofactor[bit / 64] >> (bit % 64)) & 1) r = Jac<F>::madd(r, P, false);
+        }
+        if (r.is_inf()) continue;                   // (a point of the cofactor's torsion: next candidate)
+        o[i] = r.to_aff();
+        break;
+      }
+    }
+  };
+  if (nthreads < 1) nthreads = 1;
+  std::vector<std::thread> th;
+  size_t per = (n + nthreads - 1) / nthreads;
+  for (int t = 0; t < nthreads; t++) {
+    size_t lo = t * per, hi = lo + per > n ? n : lo + per;
+    if (lo < hi) th.emplace_back(work, lo, hi);
+  }
+  for (auto& t : th) t.join();
+}
+
 static BlsFp fp_hex(const char* h) { BlsFp r; hex_to_limbs(h, r.l, 6); return BlsFp::to_mont(r); }
 static BnFp bn_hex(const char* h) { BnFp r; hex_to_limbs(h, r.l, 4); return BnFp::to_mont(r); }
 
@@ -845,6 +993,69 @@ template <> struct EndoFor<BlsFp> { static const EndoG1* get(int c) { return c =
 template <> struct EndoFor<BnFp> { static const EndoG1* get(int c) { return c == C_BN_G1 ? &endo_table().e[c] : nullptr; } static BnFp beta(int) { return endo_table().beta_bn; } };
 template <> struct EndoFor<PallasFp> { static const EndoG1* get(int c) { return c == C_PALLAS ? &endo_table().e[c] : nullptr; } static PallasFp beta(int) { return endo_table().beta_pallas; } };
 template <> struct EndoFor<VestaFp> { static const EndoG1* get(int c) { return c == C_VESTA ? &endo_table().e[c] : nullptr; } static VestaFp beta(int) { return endo_table().beta_vesta; } };
+
+// G2: lattices and Babai vectors of named/constants/bls12_381_endomorphisms.nim:39-60 and bn254_snarks_endomorphisms.nim:39-64; the psi
+// coefficients are DERIVED here, c2 = t^((p-1)/3), c3 = t^((p-1)/2) with t = 1/xi for the M-twist of BLS12-381 (xi = 1 + i) and t = xi
+// for the D-twist of BN254-Snarks (xi = 9 + i) -- tests/test_oracle_c.py checks psi(G) = [p mod r]G against the big-integer oracle
+static EndoG2 make_endo4(const char* const lat[4][4], const bool latn[4][4], const char* const bab[4], const bool babn[4]) {
+  EndoG2 e;
+  for (int i = 0; i < 4; i++) {
+    hex_to_limbs(bab[i], e.babai[i], 4);
+    e.babai_neg[i] = babn[i];
+    for (int j = 0; j < 4; j++) {
+      hex_to_limbs(lat[i][j], &e.lat[i][j], 1);
+      e.lat_neg[i][j] = latn[i][j];
+    }
+  }
+  return e;
+}
+template <class B>
+static PsiCoef<Fp2<B>> make_psi(u64 xi0, u64 xi1, bool invert) {
+  Fp2<B> t{B::from_u64(xi0), B::from_u64(xi1)};
+  if (invert) t = Fp2<B>::inv(t);
+  // (p - 1) / 3 and (p - 1) / 2 from the modulus limbs
+  const u64* P = B::ctx.p;
+  u64 pm1[B::N], e3[B::N], e2[B::N];
+  for (int i = 0; i < B::N; i++) pm1[i] = P[i];
+  pm1[0] -= 1;                                      // p is odd
+  u64 rem = 0;
+  for (int i = B::N - 1; i >= 0; i--) {            // / 3
+    u128 cur = ((u128)rem << 64) | pm1[i];
+    e3[i] = (u64)(cur / 3);
+    rem = (u64)(cur % 3);
+  }
+  for (int i = 0; i < B::N; i++) e2[i] = (pm1[i] >> 1) | (i + 1 < B::N ? pm1[i + 1] << 63 : 0);
+  return {fp2_pow<Fp2<B>>(t, e3, B::N), fp2_pow<Fp2<B>>(t, e2, B::N)};
+}
+struct EndoG2Table {
+  EndoG2 bls, bn;
+  PsiCoef<Fp2<BlsFp>> psi_bls;
+  PsiCoef<Fp2<BnFp>> psi_bn;
+};
+static const EndoG2Table& endo_g2_table() {
+  static const EndoG2Table t = []() {
+    EndoG2Table t;
+    static const char* const X = "d201000000010000";
+    static const char* const lat_bls[4][4] = {{X, "1", "0", "0"}, {"0", X, "1", "0"}, {"0", "0", X, "1"}, {"1", "0", "1", X}};
+    static const bool latn_bls[4][4] = {{false, false, false, false}, {false, false, false, false}, {false, false, false, false}, {false, false, true, true}};
+    static const char* const bab_bls[4] = {"1381204ca56cd56b533cfcc0d3e76ec2892078a5e8573b29c", "17c6becf1e01faadd63f6e522f6cfee2e", "1cfbe4f7bd0027db2", "2"};
+    static const bool babn_bls[4] = {false, true, false, false};
+    t.bls = make_endo4(lat_bls, latn_bls, bab_bls, babn_bls);
+    static const char* const A = "89d3256894d213e2"; static const char* const Bq = "44e992b44a6909f2"; static const char* const Cq = "44e992b44a6909f1"; static const char* const D = "89d3256894d213e3";
+    static const char* const lat_bn[4][4] = {{A, Bq, Cq, Cq}, {Cq, Cq, Cq, D}, {Bq, Cq, Cq, A}, {D, Cq, Bq, Cq}};
+    static const bool latn_bn[4][4] = {{false, false, true, false}, {true, false, true, true}, {false, false, false, true}, {false, true, true, true}};
+    static const char* const bab_bn[4] = {"9e80318ab0d92b9308e5da66fc7184ae46f4bda995d51bb1", "9e80318ab0d92b9555b4ca7ba3e5577f2dff291532e42728",
+                                          "9e80318ab0d92b9555b4ca7ba3e55782071c4c43fac4daff", "9e80318ab0d92b9555b4ca7ba3e5577dc170977dcef3cd3f"};
+    static const bool babn_bn[4] = {false, true, false, false};
+    t.bn = make_endo4(lat_bn, latn_bn, bab_bn, babn_bn);
+    t.psi_bls = make_psi<BlsFp>(1, 1, true);
+    t.psi_bn = make_psi<BnFp>(9, 1, false);
+    return t;
+  }();
+  return t;
+}
+template <> struct EndoG2For<Fp2<BlsFp>> { static const EndoG2* get(int c) { return c == C_BLS_G2 ? &endo_g2_table().bls : nullptr; } static const PsiCoef<Fp2<BlsFp>>& psi_coef(int) { return endo_g2_table().psi_bls; } };
+template <> struct EndoG2For<Fp2<BnFp>> { static const EndoG2* get(int c) { return c == C_BN_G2 ? &endo_g2_table().bn : nullptr; } static const PsiCoef<Fp2<BnFp>>& psi_coef(int) { return endo_g2_table().psi_bn; } };
 
 extern "C" {
 
@@ -935,5 +1146,40 @@ int oracle_scalar_mul(int curve, const void* k, const void* p, void* out) {
 }
 
 int oracle_best_bucket_bit_size(size_t n, int bits) { return best_bucket_bit_size(n, bits, true, true); }
+
+// out[i], i in [first, first + n): random points of the prime-order subgroup whose discrete logarithms nobody knows
+// (gen_points_unknown_log); BLS12-381 G1 (cofactor 0x396c8c005555e1568c00aaab0000aaab) and BN254-Snarks G1 (cofactor 1)
+int oracle_gen_points_unknown_log(int curve, u64 seed, size_t first, size_t n, void* out, int nthreads) {
+  ensure_init();
+  switch (curve) {
+    case C_BLS_G1: {
+      static const u64 h[2] = {0x8c00aaab0000aaabull, 0x396c8c005555e156ull};
+      gen_points_unknown_log<BlsFp>(4, h, 2, seed, first, n, out, nthreads); return 0; }
+    case C_BN_G1: {
+      static const u64 h[1] = {1};
+      gen_points_unknown_log<BnFp>(3, h, 1, seed, first, n, out, nthreads); return 0; }
+  }
+  return -1;
+}
+
+// out = psi(p) for a G2 point (affine, C-API layout): the endomorphism of the M = 4 pre-split (tests: psi(G) = [p mod r]G)
+int oracle_psi_g2(int curve, const void* p, void* out) {
+  ensure_init();
+  switch (curve) {
+    case C_BLS_G2: *(Aff<Fp2<BlsFp>>*)out = psi<Fp2<BlsFp>>(endo_g2_table().psi_bls, *(const Aff<Fp2<BlsFp>>*)p); return 0;
+    case C_BN_G2: *(Aff<Fp2<BnFp>>*)out = psi<Fp2<BnFp>>(endo_g2_table().psi_bn, *(const Aff<Fp2<BnFp>>*)p); return 0;
+  }
+  return -1;
+}
+// mini[4] (4 x u64 each, magnitudes) and neg[4] of the M = 4 decomposition of k (tests: sum_j (-1)^neg_j mini_j lambda^j = k mod r)
+int oracle_decompose_g2(int curve, const void* k, void* mini, int* neg) {
+  ensure_init();
+  const EndoG2* E = curve == C_BLS_G2 ? &endo_g2_table().bls : curve == C_BN_G2 ? &endo_g2_table().bn : nullptr;
+  if (!E) return -1;
+  bool ng[4];
+  decompose_endo4(*E, *(const Scalar*)k, (Scalar*)mini, ng);
+  for (int j = 0; j < 4; j++) neg[j] = ng[j] ? 1 : 0;
+  return 0;
+}
 
 }  // extern "C"

@@ -300,6 +300,50 @@ def test_all_equal_points_bug366_style():
         assert _decode(curve, "jac", multiScalarMul_vartime(name, sc2, pts)) == expect
 
 
+def test_bug366_regression_on_its_real_input_gpu():
+    """The reference's regression test itself (t_ec_shortw_jac_g2_msm_bug_366.nim:17-43): BN254-Snarks G2, N = 22529 (the N whose
+    window size 13 divides the 65-bit mini-scalars of the reference's G2 split), every point the generator, Fr scalars from
+    random_long01Seq of xoshiro512** seeded with 1234 (oracle/refprng.py restates the PRNG).  The reference compares its reference
+    and optimised MSMs; here the HIP result, through the fr_coefs and the big_coefs symbols, is compared with [sum k_i mod r]G
+    (one scalar multiplication of the big-integer oracle) and with the port running the reference's configuration."""
+    from constantine_amd import multiScalarMul_vartime
+    from tests.test_oracle_c import _bug366_inputs
+    name = "bn254_snarks_g2"
+    curve, n, ks = _bug366_inputs()
+    sc = curve.scalars_to_array(ks)
+    mont = curve.fr_scalars_to_array(ks)                      # cs: seq[Fr[BN254_Snarks]] -- the fr_coefs overload
+    pts = np.tile(curve.points_to_array([curve.gen]), (n, 1))
+    want = curve.scalar_mul(sum(ks) % curve.order, curve.gen)
+    assert _decode(curve, "jac", multiScalarMul_vartime(name, mont, pts, coord="jac", fr_coefs=True)) == want
+    assert _decode(curve, "prj", multiScalarMul_vartime(name, sc, pts, coord="prj")) == want
+    assert _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0]) == want
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_snarks_g1"])
+def test_points_with_unknown_discrete_logs_at_2pow18(name, dev, torch_cuda):
+    """Every other full-size test feeds points [s_i]G with known s_i (that is what lets the discrete-log identity check them without
+    the port).  Here 2^18 points come the way the reference's benches make theirs -- random x, square root, cofactor clearing
+    (helpers/prng_unsafe.nim:306-316, bench_elliptic_parallel_template.nim:78-102): nobody knows their logarithms, no structure for a
+    bug to hide behind.  The HIP result (device-resident, and through the Constantine symbol on host arrays) against the port."""
+    from constantine_amd import multiScalarMul_vartime_parallel
+    torch = torch_cuda
+    curve = po.CURVES[name]
+    n = 1 << 18
+    pts = cref.gen_points_unknown_log(name, 0xC0FFEE, n)
+    for i in (0, 1, n // 2, n - 1):
+        assert curve.is_on_curve(curve.aff_from_bytes(bytes(pts[i])))
+    assert curve.scalar_mul(curve.order, curve.aff_from_bytes(bytes(pts[7]))) is None
+    sc = cref.synth_scalars(0xC0FFEF, n, curve.scalar_bits)
+    expect = _aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0])
+    dp, ds = _to_dev(torch, pts), _to_dev(torch, sc)
+    assert _aff(curve, dev.msm(name, ds, dp, n, coord="aff")) == expect
+    assert _decode(curve, "jac", multiScalarMul_vartime_parallel(None, name, sc, pts, coord="jac")) == expect
+    # a ragged prefix too (not a power of two, sorted / merged differently)
+    m = n - 12345
+    expect = _aff(curve, cref.msm(name, sc[:m], pts[:m], nthreads=NT)[0])
+    assert _aff(curve, dev.msm(name, ds[:m], dp[:m], m, coord="aff")) == expect
+
+
 def test_window_sizes_and_lane_spans(dev, torch_cuda):
     """Same answer for every plan: window bits (incl. divisors of the scalar width), entries per lane, sort slices."""
     torch = torch_cuda
@@ -950,6 +994,43 @@ def test_c_program_through_the_header(tmp_path):
     assert curve.prj_from_bytes(out[720:864]) == expect          # neutral generic symbol
     assert out[864:864 + n] == b"\x01" * n                        # every generated point is in the subgroup
     assert out[864 + n:] == bytes.fromhex(evm_exp), evm_name       # the precompile symbol called from C
+
+
+def test_zal_cached_base_descriptor_from_c(tmp_path):
+    """The Halo2-ZAL caching hooks (get_base_descriptor / msm_with_cached_base / Drop; lib.rs:60-95, written out for Rust in
+    INTEGRATION.md part D2) as a C program over ctt_hip_msm_bases_create_table / ctt_hip_msm_with_bases: ONE descriptor over
+    BN254-Snarks G1 bases reused across 8 vectors of Montgomery Fr coefficients -- every result equals the oracle's, the
+    un-cached ZAL entry's, and a prefix of the bases works."""
+    import subprocess
+    from constantine_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "t_zal_cached_base"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_api", "t_zal_cached_base.c"), "-L", libdir, "-lctt_msm_hip",
+                           f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    name = "bn254_snarks_g1"
+    curve = po.CURVES[name]
+    n, m = 3000, 8
+    pts = cref.gen_points(name, 4100, n)
+    monts = [cref.synth_scalars(4200 + v, n, 250) for v in range(m)]       # Fr elements in Montgomery form, as the ZAL hands them over
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.uint64(n).tobytes())
+        f.write(np.uint64(m).tobytes())
+        f.write(pts.tobytes())
+        for mont in monts:
+            f.write(mont.tobytes())
+    subprocess.check_call([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    out = open(tmp_path / "out.bin", "rb").read()
+    assert len(out) == (2 * m + 1) * 96 + 4
+    for v, mont in enumerate(monts):
+        expect = _aff(curve, cref.msm(name, cref.fr_from_mont(name, mont), pts, nthreads=NT)[0])
+        assert curve.prj_from_bytes(out[96 * v:96 * v + 96]) == expect, v                       # msm_with_cached_base
+        assert curve.prj_from_bytes(out[96 * (m + v):96 * (m + v) + 96]) == expect, v           # msm
+    half = n // 2
+    expect = _aff(curve, cref.msm(name, cref.fr_from_mont(name, monts[0][:half]), pts[:half], nthreads=NT)[0])
+    assert curve.prj_from_bytes(out[96 * 2 * m:96 * 2 * m + 96]) == expect
+    assert int.from_bytes(out[-4:], "little", signed=True) > 0                                # the descriptor is a window table
 
 
 def test_concurrent_callers_are_serialised():

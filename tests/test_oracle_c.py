@@ -134,3 +134,72 @@ def test_edge_infinity_and_repeats():
     sc = curve.scalars_to_array([9, 9])
     out, _ = cref.msm(name, sc, pts)
     assert _aff(curve, out) is None
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g2", "bn254_snarks_g2"])
+def test_g2_endomorphism_split_of_the_port(name):
+    """Round 5 (SURVEY 8 row a16 on G2): the port applies the reference's M = 4 pre-split -- psi, the 4 x 4 lattice, Babai rounding
+    -- where the reference's dispatch does.  Pinned piece by piece against the big-integer oracle: psi(G) = [p mod r]G (the
+    eigenvalue the lattices are built for), sum_j +-m_j lambda^j = k (mod r) with 65-bit mini-scalars for edge and random k, and
+    the MSM with the split (automatic window: serial c <= 13) = the MSM without it (explicit window: the split is off) = pyoracle."""
+    curve = po.CURVES[name]
+    p, r = curve.F.p, curve.order
+    lam = p % r
+    G = curve.gen
+    Garr = curve.points_to_array([G])[0]
+    assert curve.aff_from_bytes(bytes(cref.psi_g2(name, Garr))) == curve.scalar_mul(lam, G)
+    Q = curve.scalar_mul(0xDEADBEEFCAFE, G)
+    assert curve.aff_from_bytes(bytes(cref.psi_g2(name, curve.points_to_array([Q])[0]))) == curve.scalar_mul(lam, Q)
+    rng = np.random.default_rng(8)
+    ks = [0, 1, 2, r - 1, r - 2, r, r + 1, (1 << curve.scalar_bits) - 1, 1 << (curve.scalar_bits - 1), lam, lam * lam % r, r // 2]
+    ks += [int.from_bytes(rng.bytes(32), "little") % (1 << curve.scalar_bits) for _ in range(200)]
+    for k in ks:
+        mini, neg = cref.decompose_g2(name, k)
+        assert all(m < (1 << 65) for m in mini), hex(k)
+        assert sum((-m if s else m) * pow(lam, j, r) for j, (m, s) in enumerate(zip(mini, neg))) % r == k % r, hex(k)
+    for n, seed in ((1, 3), (2, 4), (37, 5), (300, 6)):
+        pts = cref.gen_points(name, 9000 + seed, n)
+        sc = cref.synth_scalars(9100 + seed, n, curve.scalar_bits)
+        sc[0] = np.frombuffer((r - 1).to_bytes(32, "little"), dtype=np.uint8)
+        if n > 2:
+            sc[1] = 0
+            pts[2] = 0                                                  # a neutral point among the inputs
+        auto, c_auto = cref.msm(name, sc, pts, nthreads=1)              # serial, automatic c (<= 13 here): the split applies
+        assert c_auto <= 13
+        plain, _ = cref.msm(name, sc, pts, nthreads=1, c=c_auto)        # explicit c: no split
+        assert bytes(auto) == bytes(plain), n
+        par, _ = cref.msm(name, sc, pts, nthreads=4)                    # parallel dispatch (split for c in {2..6, 9, 10})
+        assert bytes(par) == bytes(plain), n
+        if n <= 37:
+            want = curve.msm_naive([int.from_bytes(bytes(x), "little") for x in sc], [curve.aff_from_bytes(bytes(x)) for x in pts])
+            assert curve.aff_from_bytes(bytes(auto)) == want, n
+
+
+def _bug366_inputs():
+    """The inputs of tests/math_elliptic_curves/t_ec_shortw_jac_g2_msm_bug_366.nim:17-43, rebuilt with the restated PRNG
+    (oracle/refprng.py): seed 1234, 22529 copies of the BN254-Snarks G2 generator, 22529 Fr scalars from random_long01Seq."""
+    from oracle import refprng
+    curve = po.CURVES["bn254_snarks_g2"]
+    rng = refprng.RngState(1234)
+    n = 22529
+    ks = [rng.random_long01seq_field(curve.order, 4) for _ in range(n)]
+    return curve, n, ks
+
+
+def test_bug366_regression_on_its_real_input():
+    """https://github.com/mratsim/constantine/issues/366: N = 22529 gives c = 13, BN254 G2 splits a 254-bit scalar into four 65-bit
+    mini-scalars, and 13 | 65 hit an off-by-one in the window count.  The port runs the reference's configuration (automatic c, the
+    M = 4 split) on the reference's input construction; all points are the generator, so the answer is [sum k_i mod r]G -- one
+    scalar multiplication of the big-integer oracle, nothing shared with the port's bucket method."""
+    curve, n, ks = _bug366_inputs()
+    assert cref.lib().oracle_best_bucket_bit_size(n, 254) == 13                    # the c of the issue
+    assert sum(1 for k in ks if k.bit_length() > 200) > n // 4                      # long runs of ones and zeros, reduced mod r
+    sc = curve.scalars_to_array(ks)
+    pts = np.tile(curve.points_to_array([curve.gen]), (n, 1))
+    want = curve.scalar_mul(sum(ks) % curve.order, curve.gen)
+    out, c_used = cref.msm("bn254_snarks_g2", sc, pts, nthreads=1)                  # multiScalarMul_vartime: c = 13, M = 4 split
+    assert c_used == 13 and curve.aff_from_bytes(bytes(out)) == want
+    out, _ = cref.msm("bn254_snarks_g2", sc, pts, nthreads=1, c=13)                 # no split: the 254-bit scalars themselves
+    assert curve.aff_from_bytes(bytes(out)) == want
+    out, _ = cref.msm("bn254_snarks_g2", sc, pts, nthreads=8)
+    assert curve.aff_from_bytes(bytes(out)) == want
