@@ -270,6 +270,22 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
+    # while rank 0 runs a leg of its own (the one-GPU reference, the in-library sharding over every GPU of the node) the other ranks
+    # wait on the HOST: an RCCL barrier would park a spinning kernel on the very GPUs rank 0's library is about to use
+    cpu_group = None
+    if world > 1 and args.backend == "nccl":
+        try:
+            cpu_group = dist.new_group(backend="gloo")
+        except Exception:   # noqa: BLE001  (no usable interface for gloo: the RCCL barrier it is)
+            cpu_group = None
+
+    def idle_barrier():
+        if world > 1:
+            if cpu_group is not None:
+                dist.barrier(group=cpu_group)
+            else:
+                dist.barrier()
+
     def timed_leg(leg_strong, lg, exchange=True, solo=False):
         """One timed loop: `steps` complete MSMs with two in flight.  leg_strong: 2^lg pairs in total over the ranks, else 2^lg per
         rank.  solo: this rank alone, all 2^lg pairs, no collective (the same-run one-GPU reference of an N-GPU line).
@@ -414,7 +430,7 @@ def main():
             if rank == 0 and lg <= 22:
                 solo = timed_leg(True, lg, solo=True)
                 solo_ms = solo["dt"] / args.steps * 1e3
-            dist.barrier()
+            idle_barrier()
             out["strong_bound"] = {
                 "ms_per_step_shards_without_exchange": own_ms,
                 "ms_per_step_one_gpu_same_run": solo_ms,
@@ -454,11 +470,12 @@ def main():
                         hp.append((time.perf_counter() - t1) * 1e3)
                     res_h[tag] = statistics.median(hp[2:])
                 set_devices([])
+                torch.cuda.set_device(local_rank)
                 out["hostptr_sharded_ms"] = {"one_device": res_h["one_device"], "all_devices": res_h["all_devices"],
                                              "devices": torch.cuda.device_count(),
                                              "note": f"median of 5 calls of the Constantine symbol on pageable host arrays, 2^{lg} pairs, from ONE process "
                                                      "(rank 0; the other ranks idle): the library's own sharding over the node's GPUs, PCIe included"}
-            dist.barrier()
+            idle_barrier()
 
     if rank == 0:
         # ---- roofline of the dominant kernel (bucket accumulation, k_accum); N > 1: rank 0's launches (every rank runs the same

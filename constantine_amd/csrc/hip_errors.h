@@ -32,6 +32,17 @@ void set_last_error(int code, const char* fmt, ...) __attribute__((format(printf
 // a failed HIP runtime call: last error = ERR_HIP_FAILURE (ERR_OUT_OF_MEMORY for an allocation), then throw or abort (see above)
 [[noreturn]] void hip_failed(const char* expr, const char* what, int hip_error_is_oom, const char* file, int line);
 
+// The calling thread's current HIP device is the caller's business (a host program with HIP code of its own, torch): an entry point
+// selects its context's device for the duration of the call and puts the previous one back (round 5; rounds 1-4 left the context's
+// device selected -- after ctt_hip_msm_set_devices({0..7}) a torch process found itself on GPU 7).
+struct DeviceScope {
+  int prev = -1, dev;
+  explicit DeviceScope(int device);
+  ~DeviceScope();
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 struct ErrorGuard {
   ErrorGuard() { error_state().guard++; }
   ~ErrorGuard() { error_state().guard--; }

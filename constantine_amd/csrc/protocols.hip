@@ -531,7 +531,7 @@ int kzg_context_build(ctt_eth_kzg_context_struct** out, const uint8_t* srs, int 
   if (!c->bases) return fail(GPU_UNAVAILABLE);
   c->domain = domain_brp();
   try {
-    PROT_HIP_CHECK(hipSetDevice(device));
+    DeviceScope device_scope(device);
     PROT_HIP_CHECK(hipMalloc(&c->d_domain, (size_t)N_BLOB * 32));
     PROT_HIP_CHECK(hipMalloc(&c->d_poly, (size_t)N_BLOB * 32));
     PROT_HIP_CHECK(hipMalloc(&c->d_q, (size_t)N_BLOB * 32));
@@ -547,7 +547,7 @@ int kzg_context_build(ctt_eth_kzg_context_struct** out, const uint8_t* srs, int 
 // -> KZG_Success, or GPU_UNAVAILABLE when the GPU refused (nothing written)
 int kzg_prove(ctt_eth_kzg_context_struct* c, uint8_t proof[48], uint64_t y_c[4], const uint8_t* poly_le, const uint64_t z_c[4]) {
   std::lock_guard<std::mutex> lock(c->mu);
-  PROT_HIP_CHECK(hipSetDevice(c->device));
+  DeviceScope device_scope(c->device);
   hipStream_t s = (hipStream_t)ctt_hip_msm_stream(c->hip);
   if (!s) return GPU_UNAVAILABLE;                       // the context was lost to an earlier HIP failure
   PROT_HIP_CHECK(hipMemcpyAsync(c->d_poly, poly_le, (size_t)N_BLOB * 32, hipMemcpyHostToDevice, s));
@@ -688,7 +688,7 @@ void ctt_eth_kzg_context_delete(ctt_eth_kzg_context_struct* c) {
   if (!c) return;
   (void)gpu_guarded([&]() {
     std::lock_guard<std::mutex> lock(c->mu);
-    (void)hipSetDevice(c->device);
+    DeviceScope device_scope(c->device);
     ctt_hip_msm_sync(c->hip);
     if (c->bases) ctt_hip_msm_bases_destroy(c->hip, c->bases);
     if (c->d_domain) (void)hipFree(c->d_domain);
