@@ -16,7 +16,12 @@ def build():
     if os.environ.get("EMU_LIB"):   # an emulator built elsewhere with other options (experiments)
         return os.environ["EMU_LIB"]
     jobs = str(max(1, min(8, os.cpu_count() or 1)))
-    subprocess.check_call(["make", "-s", "-j", jobs, "-C", HERE])
+    # one builder at a time: the two ranks of tests/test_dist_gloo.py import this module at the same moment, and two `make`s writing
+    # the same objects handed one of them a half-written library once (the test then waited out its 300 s queue timeout)
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-j", jobs, "-C", HERE])
     return os.path.join(HERE, "libmsm_emu.so")
 
 

@@ -58,6 +58,8 @@ def _worker(rank, world, port, name, n, q):
 @pytest.mark.parametrize("name,n", [("bls12_381_g1", 101), ("bn254_snarks_g1", 64)])
 def test_sharded_msm_two_ranks(name, n):
     from oracle import cref
+    from tests.emu import emu
+    emu.lib()                       # built here, before the ranks start (they would otherwise both run `make`)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
