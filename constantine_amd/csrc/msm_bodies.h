@@ -157,7 +157,7 @@ struct SortArgs {
   uint32_t* gbase;          // [W][NG+1] group start inside the set
   uint32_t* bstart;         // [W][B+1]
   uint32_t* entries;        // [W][nent]
-  uint32_t* maxcount;       // [2]: largest bucket; scratch word
+  uint32_t* maxcount;       // [4]: [0] largest bucket, [2] the head merge's queue count; zeroed by the sort's first kernel (k_part_count)
   uint32_t cap, big;        // k_group_sort: entries per LDS tile; buckets above `big` bypass the LDS image
   uint32_t xcd_map = 1;     // partition kernels: neighbouring slices on one XCD (msm_engine.hip part_slice_of_block); 0 = slice b to block b
   uint32_t staged = 1;      // pass A sweep 2 through an LDS image of the block's output (k_part_scatter_staged); 0 = one store per record

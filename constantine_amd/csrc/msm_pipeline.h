@@ -67,6 +67,11 @@ struct MsmOptions {
   // head merge: 0 = the queue form (tail merge + one lane per chain with work left, msm_bodies.h merge_tail_queue_body) when the plan
   // expects chains of at most merge_lmax heads, else the tree; 1 = the queue form always; 2 = the tree always.  merge_lmax 0 = 8.
   int merge_chain = 0, merge_lmax = 0;
+  // experiment knob (round 5, measured and NOT adopted): 1 = small pipelined MSMs (up to 2^17 pairs) put the FIRST reduction pass on the tail
+  // stream too, so that the next MSM's sort starts right behind the head merge.  Same box, ms per MSM with two in flight, off / on:
+  // BLS12-381 G1 2^16 0.466-0.473 / 0.480, 2^17 0.654-0.657 / 0.676-0.680, BN254 2^16 0.345 / 0.350 -- the fork's event pair costs what the
+  // 25 us of overlap give (gpurun_out/r5i)
+  int pyr0_tail = 0;
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -563,7 +568,7 @@ struct MsmEngine {
     st.d_bstart = (uint32_t*)need(bstartS[sl], (size_t)W * (B + 1) * 4);
     uint32_t* d_entries = (uint32_t*)need(entries, (size_t)W * p.nent * 4);
     st.d_maxcount = (uint32_t*)need(maxcountS[sl], 256);
-    bk.memset0(st.d_maxcount, 16);   // [0] largest bucket, [2] the head merge's queue count
+    // (d_maxcount: [0] the largest bucket, [2] the head merge's queue count -- zeroed by the sort's first kernel: no fill launch)
     sa.bstart = st.d_bstart; sa.entries = d_entries; sa.maxcount = st.d_maxcount;
     // the sort leaves the empty buckets of the set neutral (round 5; a fill launch of the whole set before).  Not for a later
     // slice of a host-pointer MSM (into): its runs continue the stored sums.  The set is this slot's: the previous MSM of the
@@ -664,11 +669,12 @@ struct MsmEngine {
     // under wide passes), a quarter of the overlap is what remains.
     static const bool wide_early = !(getenv("CTT_HIP_MSM_WIDE_EARLY") && atoi(getenv("CTT_HIP_MSM_WIDE_EARLY")) == 0);
     bool forked = forked_early, marked = false;
+    const bool first_pass_on_tail = opt.pyr0_tail == 1 && p.n <= (1u << 17) && !p.merged;   // (MsmOptions::pyr0_tail: measured, off)
     for (int pass = 0; pass <= p.c - 2; pass++) {
       PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass, 1u};
       const uint32_t ntasks = pyr_pass_tasks(B, p.c, pass);
       const bool narrow = bk.pyr_goes_to_tail(ntasks, W);
-      if (pipelining && !forked && pass > 0 && (narrow || wide_early)) {
+      if (pipelining && !forked && (pass > 0 || first_pass_on_tail) && (narrow || wide_early)) {
         bk.tail_begin();
         forked = true;
       }

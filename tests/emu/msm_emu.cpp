@@ -80,7 +80,7 @@ struct EmuBackend {
       }
     } zero_empty{a};
     std::vector<uint32_t> dg(n), cnt(B);
-    *a.maxcount = 0;
+    for (int q = 0; q < 4; q++) a.maxcount[q] = 0;   // (the sort's first kernel zeroes the MSM's counters: SortArgs::maxcount)
     if (a.merged) {
       // window table: every digit window goes to the one bucket set, entry = table row w*id_stride + j
       std::vector<uint32_t> all((size_t)a.Wd * n);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of the in-tree library against tools/libctt_msm_hip_prev.so (built from an earlier commit)
 ARGS="$@"
-for rep in 1 2 3; do
+for rep in $(seq 1 ${REPS:-3}); do
   for which in prev new; do
     if [ $which = prev ]; then export CTT_MSM_HIP_LIB=$PWD/tools/libctt_msm_hip_prev.so CTT_MSM_HIP_ALLOW_OLD_ABI=1; else unset CTT_MSM_HIP_LIB CTT_MSM_HIP_ALLOW_OLD_ABI; fi
     python bench.py --steps 10 --warmup 2 --no-cpu-baseline $ARGS 2>/dev/null | \

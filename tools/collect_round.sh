@@ -62,7 +62,7 @@ sq pallas_2pow20 --curve pallas
 sq bls12_381_g2_2pow20 --curve bls12_381_g2
 sq bls12_381_g1_2pow16 --log2n 16
 sq bls12_381_g1_2pow24 --log2n 24
-for cfg in "bn254_snarks_g1 22" "pallas 20" "bls12_381_g2 20" "bls12_381_g1 16" "bls12_381_g1 18"; do
+for cfg in "bn254_snarks_g1 22" "pallas 20" "bls12_381_g2 20" "bls12_381_g1 16" "bls12_381_g1 17" "bls12_381_g1 18"; do
   set -- $cfg
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_$1" -o p -- python "$REPO/bench.py" --curve $1 --log2n $2 --steps 10 --warmup 2 \
       --no-cpu-baseline --no-latency > /dev/null 2>> "$OUT/prof.log" )
@@ -102,5 +102,12 @@ timeout 300 python tools/bench_hostptr.py > "$OUT/hostptr_$TAG.txt" 2>> "$OUT/be
   timeout 300 python tools/bench_table.py pallas 20 0
   timeout 300 python tools/bench_table.py bls12_381_g2 18 0
 } 2>> "$OUT/bench.err" | grep '^{' > "$OUT/table_$TAG.jsonl"
+# the N-GPU line's code path end to end on this one GPU: two ranks sharing device 0 with a gloo exchange (a plumbing check, not a scaling point)
+timeout 300 python bench.py --gpus 2 --all-ranks-on-device 0 --backend gloo --steps 10 --warmup 2 > "$OUT/bench_${TAG}_2ranks_one_gpu_gloo.json" 2>> "$OUT/bench.err"
+# same box, the previous round's library next to this one (tools/libctt_msm_hip_prev.so, built from the previous round's commit)
+if [ -f tools/libctt_msm_hip_prev.so ]; then
+  { for a in "--log2n 16" "--log2n 17" "--log2n 18" "--log2n 19" "" "--curve bn254_snarks_g1 --log2n 20" "--curve bn254_snarks_g1 --log2n 22" "--curve pallas" "--curve bls12_381_g2 --log2n 18"; do
+      echo "== bench.py $a (value M/s, ms per MSM with two in flight, stage times of the timed loop) =="; REPS=2 bash tools/ab_prev.sh --no-latency $a; done; } > "$OUT/ab_prev_vs_${TAG}.txt" 2>> "$OUT/bench.err"
+fi
 find "$OUT/prof" -name "*.db" -delete 2>/dev/null   # the rocpd databases are large; the summaries are what is kept
 tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench_$TAG.json"
