@@ -185,6 +185,10 @@ static inline uint32_t plan_merge_lmax(const MsmPlan& p, const MsmOptions& o) {
   const uint32_t lmax = o.merge_lmax > 0 ? (uint32_t)o.merge_lmax : 8u;
   if (o.merge_chain == 1) return lmax;
   if (o.merge_chain == 2) return 0u;
+  // not over the quadratic extensions (acc_ns is the engine's curve constant: 0.47-0.5 for the G2 curves): a full addition there is 3.3 x a G1
+  // one, and the queue kernel's one-lane additions cost more than the tree's four-lane steps -- same box, BLS12-381 G2 2^18, ms per MSM with
+  // two in flight, tree / queue: 2.96 / 3.02, and 3.22-3.29 / 3.32-3.36 in the A/B against the round-4 library (profiles/ab_prev_vs_r05_first.txt)
+  if (o.acc_ns >= 0.3) return 0u;
   return (p.merge_steps <= 30 && (1u << p.merge_steps) <= lmax) ? lmax : 0u;
 }
 
