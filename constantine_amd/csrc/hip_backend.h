@@ -354,6 +354,28 @@ template <class F>
 __global__ void __launch_bounds__(RED_BLOCK) k_merge_finish(MergeArgs<F> a, uint32_t first_d) {
   merge_finish_body<F>(a, blockIdx.x, first_d, threadIdx.x, blockDim.x, []() { __syncthreads(); });
 }
+// the queue kernel with FOUR lanes per chain (xyzz_add_quad_reg: the running sum resident in the registers of the quad, the next head
+// from memory): the queue holds a few ten thousand chains of one or two additions -- latency, not throughput -- and a four-lane addition is
+// 4 products deep instead of 14.  Same box, merge stage of a blocking 2^16-pair call, one lane / four lanes per chain: see DESIGN.md 4.4.
+template <class F>
+__global__ void __launch_bounds__(EC_BLOCK) k_merge_queue_quad(MergeArgs<F> a, uint32_t lmax) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t qi = lane >> 2;
+  const int role = (int)(lane & 3u);
+  if (qi >= *a.qcount) return;                  // (whole quads leave together)
+  const uint32_t slot = a.queue[qi];
+  const uint32_t w = slot / a.G, s = slot - w * a.G;
+  const uint32_t b = a.hkey[slot];
+  const uint32_t* bs = a.bucket_start + (uint64_t)w * (a.B + 1);
+  const uint32_t len = chain_last(bs, a.K, b) - s + 1;
+  if (len > lmax) return;                       // merge_long_body's
+  XYZZ<F> acc = a.heads[slot];
+  for (uint32_t i = 1; i < len; i++) {
+    const XYZZ<F> h = a.heads[slot + i];
+    xyzz_add_quad_reg<F>(acc, h, role);
+  }
+  if (role == 0) a.buckets[(uint64_t)w * a.B + b] = acc;
+}
 // the chains the chain form left (more than lmax heads: unusual inputs), one workgroup per window (msm_bodies.h merge_long_body)
 template <class F>
 __global__ void __launch_bounds__(RED_BLOCK) k_merge_long(MergeArgs<F> a, uint32_t lmax) {
@@ -678,9 +700,10 @@ struct HipBackend {
     HIP_CHECK(hipGetLastError());
   }
   template <class F>
-  void launch_merge_queue(const MergeArgs<F>& a, uint32_t W, uint32_t lmax) {
+  void launch_merge_queue(const MergeArgs<F>& a, uint32_t W, uint32_t lmax, bool quad) {
     // at most every second lane starts a chain of two or more heads
-    hipLaunchKernelGGL(k_merge_queue<F>, grid1(merge_queue_capacity(W, a.G), EC_BLOCK), dim3(EC_BLOCK), 0, cur(), a, lmax);
+    if (quad) hipLaunchKernelGGL(k_merge_queue_quad<F>, grid1(merge_queue_capacity(W, a.G) * 4u, EC_BLOCK), dim3(EC_BLOCK), 0, cur(), a, lmax);
+    else hipLaunchKernelGGL(k_merge_queue<F>, grid1(merge_queue_capacity(W, a.G), EC_BLOCK), dim3(EC_BLOCK), 0, cur(), a, lmax);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>

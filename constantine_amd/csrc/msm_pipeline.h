@@ -67,6 +67,7 @@ struct MsmOptions {
   // head merge: 0 = the queue form (tail merge + one lane per chain with work left, msm_bodies.h merge_tail_queue_body) when the plan
   // expects chains of at most merge_lmax heads, else the tree; 1 = the queue form always; 2 = the tree always.  merge_lmax 0 = 8.
   int merge_chain = 0, merge_lmax = 0;
+  int merge_queue_quad = 0;   // the queue kernel with four lanes per chain (hip_backend.h k_merge_queue_quad): 0 / 1 = on, 2 = one lane per chain
   // experiment knob (round 5, measured and NOT adopted): 1 = small pipelined MSMs (up to 2^17 pairs) put the FIRST reduction pass on the tail
   // stream too, so that the next MSM's sort starts right behind the head merge.  Same box, ms per MSM with two in flight, off / on:
   // BLS12-381 G1 2^16 0.466-0.473 / 0.480, 2^17 0.654-0.657 / 0.676-0.680, BN254 2^16 0.345 / 0.350 -- the fork's event pair costs what the
@@ -628,7 +629,7 @@ struct MsmEngine {
       ma.queue = (uint32_t*)need(mqueue, (size_t)merge_queue_capacity(p.W, p.G) * 4);
       ma.qcount = st.d_maxcount + 2;     // (zeroed with the largest-bucket word before the sort)
       bk.template launch_merge_tail_queue<FD>(ma, p.W);
-      bk.template launch_merge_queue<FD>(ma, p.W, p.merge_lmax);
+      bk.template launch_merge_queue<FD>(ma, p.W, p.merge_lmax, opt.merge_queue_quad != 2);
       bk.template launch_merge_long<FD>(ma, p.W, p.merge_lmax);
     } else {
       bk.template launch_merge_tail<FD>(ma, p.W);

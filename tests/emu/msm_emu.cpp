@@ -169,7 +169,7 @@ struct EmuBackend {
       }
   }
   template <class F>
-  void launch_merge_queue(const MergeArgs<F>& a, uint32_t W, uint32_t lmax) {
+  void launch_merge_queue(const MergeArgs<F>& a, uint32_t W, uint32_t lmax, bool /*quad: a GPU launch shape*/) {
     for (uint32_t qi = 0; qi < merge_queue_capacity(W, a.G); qi++) merge_queue_body<F>(a, qi, lmax);
   }
   template <class F>
