@@ -507,8 +507,12 @@ struct HipBackend {
     wide_pending = false;   // (the end of the tail is behind its wide passes)
   }
   static uint32_t quad_threshold() {
-    static const uint32_t v = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 24576u;
-    return v;  // measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768
+    static const uint32_t v = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 49152u;
+    // rounds 1-4: 24576 (measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768).  Round 5 swept it again with the
+    // small sizes in view (profiles/pyr_quad_threshold_r05.txt, same box, ms per MSM with two in flight at 24576 / 49152 / 131072):
+    // 2^16 0.443-0.454 / 0.439-0.450 / 0.436-0.448, 2^17 0.631 / 0.619 / 0.614, 2^18 0.978-0.993 / 0.974-0.986 / 0.965-0.989, 2^20 2.79-2.88 /
+    // 2.83-2.89 / 2.89-2.90 (blocking 3.13-3.17 / 3.14-3.16 / 3.23-3.25): 49152 takes the small sizes' 2 % and leaves 2^20 where it was
+    return v;
   }
   static bool pyr_is_narrow(uint32_t ntasks, uint32_t W) { return (uint64_t)ntasks * W <= quad_threshold(); }
   // passes with at most this many additions (all windows) go to the tail stream
