@@ -485,6 +485,33 @@ struct HipBackend {
     on_aux = false;
     tail_pending = true;
   }
+  // Front stream (round 5): the conversion and the sort of a SMALL MSM that a caller keeps in flight run here, beside the previous MSM's
+  // head merge and first reduction pass, instead of behind them on the main stream.  They need the coefficients and points only, write
+  // nothing the previous MSM still reads once its accumulation has ended (front_begin waits for that), and are memory- / LDS-bound where
+  // the merge is a latency chain of additions: the 60-70 us of a 2^16-2^17-pair MSM's sort drop out of the step.  front_end joins:
+  // the accumulation on the main stream waits for the sort.  (The large sizes get the same overlap from the early tail, msm_pipeline.h.)
+  hipStream_t srt = nullptr;
+  hipEvent_t ev_accum_done = nullptr, ev_front_done = nullptr;
+  bool on_front = false, accum_marked = false;
+  hipStream_t front() const { return on_front ? srt : stream; }
+  void front_begin() {
+    // the previous accumulation has read the shared entry list / records: its own event when it left one (accum_mark), else -- the first
+    // MSM of a pipeline -- everything the main stream holds now (no overlap for that one, same order as without the front stream)
+    if (!accum_marked) HIP_CHECK(hipEventRecord(ev_accum_done, stream));
+    HIP_CHECK(hipStreamWaitEvent(srt, ev_accum_done, 0));
+    on_front = true;
+  }
+  void front_end() {
+    HIP_CHECK(hipEventRecord(ev_front_done, srt));
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_front_done, 0));
+    on_front = false;
+  }
+  // behind every accumulate launch: with an event for the next MSM's front stage when one is expected (an event record is a barrier
+  // packet in the queue: not for callers that do not pipeline small MSMs)
+  void accum_mark(bool wanted) {
+    if (wanted) HIP_CHECK(hipEventRecord(ev_accum_done, stream));
+    accum_marked = wanted;
+  }
   // "the wide reduction passes of the tail are done": what the next MSM's accumulation waits for when the tail starts early
   // (MsmEngine::reduce_buckets) -- the narrow rest of the tail may run beside that accumulation, the wide passes may not
   hipEvent_t ev_wide_done = nullptr;
@@ -616,13 +643,13 @@ struct HipBackend {
     }
     if (!stage_on(s)) return;
     const int ch = (s == ST_TOTAL || s == ST_REDUCE) ? 0 : chunk;
-    HIP_CHECK(hipEventRecord(ev_begin[slot][s][ch], cur()));
+    HIP_CHECK(hipEventRecord(ev_begin[slot][s][ch], (s == ST_DIGITS || s == ST_SORT) ? front() : cur()));
     ev_used[slot][s] |= 1u << ch;
   }
   void stage_end(int slot, int s) {
     if (!stage_on(s)) return;
     const int ch = (s == ST_TOTAL || s == ST_REDUCE) ? 0 : chunk;
-    HIP_CHECK(hipEventRecord(ev_end[slot][s][ch], cur()));
+    HIP_CHECK(hipEventRecord(ev_end[slot][s][ch], (s == ST_DIGITS || s == ST_SORT) ? front() : cur()));
   }
   // stage times of the MSM that used `slot` (call after its finish())
   void collect_timings(int slot) {
@@ -652,13 +679,13 @@ struct HipBackend {
 
   template <class Fr>
   void launch_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
-    hipLaunchKernelGGL(k_fr_from_mont<Fr>, grid1(n, 256), dim3(256), 0, stream, in, out, n);
+    hipLaunchKernelGGL(k_fr_from_mont<Fr>, grid1(n, 256), dim3(256), 0, front(), in, out, n);
     HIP_CHECK(hipGetLastError());
   }
   template <class F, class FD>
   void launch_convert(const Affine<F>* in, void* out, uint32_t n) {
     hipLaunchKernelGGL((k_convert_points<F, FD>), grid1(n, CONVERT_BLOCK), dim3(CONVERT_BLOCK),
-                       (size_t)CONVERT_BLOCK * gather_stride<FD>(), stream, in, out, n);
+                       (size_t)CONVERT_BLOCK * gather_stride<FD>(), front(), in, out, n);
     HIP_CHECK(hipGetLastError());
   }
   template <class F>

@@ -67,7 +67,8 @@ struct MsmOptions {
   // head merge: 0 = the queue form (tail merge + one lane per chain with work left, msm_bodies.h merge_tail_queue_body) when the plan
   // expects chains of at most merge_lmax heads, else the tree; 1 = the queue form always; 2 = the tree always.  merge_lmax 0 = 8.
   int merge_chain = 0, merge_lmax = 0;
-  int merge_queue_quad = 0;   // the queue kernel with four lanes per chain (hip_backend.h k_merge_queue_quad): 0 / 1 = on, 2 = one lane per chain
+  int merge_queue_quad = 0;
+  int front_side = 0;         // small pipelined MSMs: conversion + sort on the front stream (0 automatic, 1 always when pipelining, 2 never)   // the queue kernel with four lanes per chain (hip_backend.h k_merge_queue_quad): 0 / 1 = on, 2 = one lane per chain
   // experiment knob (round 5, measured and NOT adopted): 1 = small pipelined MSMs (up to 2^17 pairs) put the FIRST reduction pass on the tail
   // stream too, so that the next MSM's sort starts right behind the head merge.  Same box, ms per MSM with two in flight, off / on:
   // BLS12-381 G1 2^16 0.466-0.473 / 0.480, 2^17 0.654-0.657 / 0.676-0.680, BN254 2^16 0.345 / 0.350 -- the fork's event pair costs what the
@@ -526,10 +527,13 @@ struct MsmEngine {
   // points_arrive (submit_host, a slice copied by the submitting thread): the points of this slice are not on the device yet -- the
   // digits and the sort need the coefficients only, so they are enqueued first, the hook then copies the points (the thread sits in that
   // copy while the GPU sorts) and the conversion follows the sort instead of preceding it.
+  // front_side (submit(), small MSMs kept in flight): conversion, digits and sort on the backend's front stream, beside the previous MSM's
+  // head merge and first reduction pass (HipBackend::front_begin has the ordering argument)
   Staged accumulate_pairs(int sl, const MsmPlan& p, const uint32_t* d_coefs, bool coef_is_fr, const Affine<F>* d_points_in,
                           const void* d_prepared, void* d_converted, XYZZ<FD>* d_buckets, bool into = false,
-                          const std::function<void()>* points_arrive = nullptr) {
+                          const std::function<void()>* points_arrive = nullptr, bool front_side = false) {
     const uint32_t n = p.n, W = p.W, B = p.B;
+    if (front_side) bk.front_begin();
     bk.stage_begin(sl, ST_DIGITS);
     const uint32_t* d_scalars = d_coefs;
     if (coef_is_fr) {
@@ -588,6 +592,7 @@ struct MsmEngine {
       }
     }
     bk.stage_end(sl, ST_SORT);
+    if (front_side) bk.front_end();     // the accumulation below (main stream) waits for the sort
 
     // The previous MSM's tail (narrow reduction passes + result copy on the backend's second stream) has had this MSM's
     // conversion and sort to run underneath; the accumulation must not start before it is done: k_accum takes every
@@ -610,6 +615,7 @@ struct MsmEngine {
     st.d_tkey = (uint32_t*)need(tkey, (size_t)W * p.G * 4);
     AccumArgs<FD> aa{d_entries, st.d_bstart, d_points, point_stride, d_buckets, st.d_heads, st.d_tails, st.d_hkey, st.d_tkey, p.nent, B, p.K, p.G};
     bk.template launch_accum<FD>(aa, W, into);
+    bk.accum_mark(front_side);          // (what the next small MSM's front stage waits for: the shared entry list and records are free again)
     bk.stage_end(sl, ST_ACCUM);
     return st;
   }
@@ -780,7 +786,10 @@ struct MsmEngine {
         if (!d_prepared) d_converted = need(cpoints, (size_t)n * gather_stride<FD>());
       }
       XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(bucketsS[sl], (size_t)p.W * p.B * sizeof(XYZZ<FD>));
-      const Staged st = accumulate_pairs(sl, p, d_coefs, coef_is_fr, d_points_in, d_prepared, d_converted, d_buckets);
+      // Round 5: a TINY MSM (up to 2^13 pairs) submitted while another is in flight runs its conversion and sort on the front stream, beside
+      // that MSM's head merge and first reduction pass (front_side_applies has the measurements: -5 % at 2^10, -11 % at 2^12, a loss from 2^16 on).
+      const bool front_side = front_side_applies(p);
+      const Staged st = accumulate_pairs(sl, p, d_coefs, coef_is_fr, d_points_in, d_prepared, d_converted, d_buckets, /*into=*/false, nullptr, front_side);
       // Early tail (round 4): a caller that keeps large MSMs in flight gets the head merge and EVERY reduction pass of this MSM on the
       // tail stream, so that the next MSM's conversion and sort -- memory-bound -- start right behind this accumulation instead of
       // behind the merge and the widest pass (VALU-bound additions, 0.16 ms at 2^20).  What those stages read is per slot (bstartS,
@@ -802,6 +811,19 @@ struct MsmEngine {
   // 1.70 / 1.63, 2^20 2.90 / 2.81 (-3.1 %), BN254 2^20 1.62 / 1.58, 2^22 5.39 / 5.25, Pallas 2^20 1.46 / 1.40 (-3.9 %), 2^18 1.011 / 0.998;
   // but BLS12-381 G1 2^22 10.5 / 10.6 and G2 2^20 9.45 / 9.49: with a 8-10 ms accumulation the 0.16 ms are 1.5 % at best and the sort
   // (0.5 ms at 2^22) running beside the widest pass loses more than the overlap gives.
+  bool front_side_applies(const MsmPlan& p) const {
+    static const int mode = getenv("CTT_HIP_MSM_FRONT") ? atoi(getenv("CTT_HIP_MSM_FRONT")) : 1;   // 0 off, 1 automatic, 2 whenever pipelining
+    if (mode == 0 || opt.front_side == 2) return false;
+    if (!(slots[0].busy && slots[1].busy)) return false;    // a lone blocking call has nothing to run beside
+    if (mode >= 2 || opt.front_side == 1) return true;
+    // Measured (profiles/front_stream_small_msm_r05.txt, same box, ms per MSM with two in flight, main stream only / front stream): it pays for
+    // the SMALLEST MSMs only -- BLS12-381 G1 2^10 0.277 / 0.263, 2^12 0.327-0.338 / 0.293-0.296 -- is level at 2^14 (0.388-0.393 / 0.383-0.386) and
+    // loses above: 2^16 0.470 / 0.494, 2^17 0.637 / 0.664, G2 2^16 1.077 / 1.227.  The overlap is real (the sort leaves the main stream's chain), but
+    // with a second hardware queue active the dependent kernels of BOTH chains start later (round 3 saw the same with two engine lanes: 50-70 us
+    // between dependent launches): below 2^13 pairs the chains are all launch latency and the overlap wins, above it the delayed launches cost
+    // more than the hidden sort.
+    return p.n <= (1u << 13) && opt.acc_ns < 0.3 && !early_tail_applies(p);
+  }
   bool early_tail_applies(const MsmPlan& p) const {
     static const int mode = getenv("CTT_HIP_MSM_EARLY_TAIL") ? atoi(getenv("CTT_HIP_MSM_EARLY_TAIL")) : 1;   // 0 off, 1 automatic, 2 whenever pipelining
     if (mode == 0 || opt.early_tail == 0) return false;

@@ -32,6 +32,9 @@ struct EmuBackend {
   bool tail_forked() const { return false; }
   void wide_mark() {}
   void wide_wait() {}
+  void front_begin() {}
+  void front_end() {}
+  void accum_mark(bool) {}
   void stage_chunk(int) {}
   void d2h_sync(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void h2d(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
