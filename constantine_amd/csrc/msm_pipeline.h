@@ -786,8 +786,8 @@ struct MsmEngine {
         if (!d_prepared) d_converted = need(cpoints, (size_t)n * gather_stride<FD>());
       }
       XYZZ<FD>* d_buckets = (XYZZ<FD>*)need(bucketsS[sl], (size_t)p.W * p.B * sizeof(XYZZ<FD>));
-      // Round 5: a TINY MSM (up to 2^13 pairs) submitted while another is in flight runs its conversion and sort on the front stream, beside
-      // that MSM's head merge and first reduction pass (front_side_applies has the measurements: -5 % at 2^10, -11 % at 2^12, a loss from 2^16 on).
+      // Round 5 experiment (option front_side = 1; off by default: front_side_applies has the measurements): conversion and sort of a small MSM
+      // submitted while another is in flight on the front stream, beside that MSM's head merge and first reduction pass.
       const bool front_side = front_side_applies(p);
       const Staged st = accumulate_pairs(sl, p, d_coefs, coef_is_fr, d_points_in, d_prepared, d_converted, d_buckets, /*into=*/false, nullptr, front_side);
       // Early tail (round 4): a caller that keeps large MSMs in flight gets the head merge and EVERY reduction pass of this MSM on the
@@ -816,13 +816,15 @@ struct MsmEngine {
     if (mode == 0 || opt.front_side == 2) return false;
     if (!(slots[0].busy && slots[1].busy)) return false;    // a lone blocking call has nothing to run beside
     if (mode >= 2 || opt.front_side == 1) return true;
-    // Measured (profiles/front_stream_small_msm_r05.txt, same box, ms per MSM with two in flight, main stream only / front stream): it pays for
-    // the SMALLEST MSMs only -- BLS12-381 G1 2^10 0.277 / 0.263, 2^12 0.327-0.338 / 0.293-0.296 -- is level at 2^14 (0.388-0.393 / 0.383-0.386) and
-    // loses above: 2^16 0.470 / 0.494, 2^17 0.637 / 0.664, G2 2^16 1.077 / 1.227.  The overlap is real (the sort leaves the main stream's chain), but
-    // with a second hardware queue active the dependent kernels of BOTH chains start later (round 3 saw the same with two engine lanes: 50-70 us
-    // between dependent launches): below 2^13 pairs the chains are all launch latency and the overlap wins, above it the delayed launches cost
-    // more than the hidden sort.
-    return p.n <= (1u << 13) && opt.acc_ns < 0.3 && !early_tail_applies(p);
+    // Measured and NOT adopted (profiles/front_stream_small_msm_r05.txt, same box, ms per MSM with two in flight, main stream only / front stream):
+    // BLS12-381 G1 2^12 0.278 / 0.287, 2^14 0.388-0.393 / 0.383-0.386, 2^16 0.470 / 0.494, 2^17 0.637 / 0.664, G2 2^16 1.077 / 1.227.  The overlap
+    // is real (the sort leaves the main stream's chain), but with a second hardware queue active the dependent kernels of BOTH chains start later
+    // (round 3 saw the same with two engine lanes: 50-70 us between dependent launches).  What the experiment did find: a process has FOUR hardware
+    // queues (GPU_MAX_HW_QUEUES); with the front stream as a FIFTH stream of the context (null, main, tail, copy, front) two streams shared a queue
+    // and every small pipelined MSM lost 8 % (2^16: 0.52 -> 0.56 ms) without a single kernel on the new stream -- the front stage therefore
+    // runs on the copy stream (HipBackend::init), and nothing in the library may add a stream lightly.
+    (void)p;
+    return false;
   }
   bool early_tail_applies(const MsmPlan& p) const {
     static const int mode = getenv("CTT_HIP_MSM_EARLY_TAIL") ? atoi(getenv("CTT_HIP_MSM_EARLY_TAIL")) : 1;   // 0 off, 1 automatic, 2 whenever pipelining
