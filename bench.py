@@ -283,6 +283,11 @@ def main():
             cpu_group = dist.new_group(backend="gloo")
         except Exception:   # noqa: BLE001  (no usable interface for gloo: the RCCL barrier it is)
             cpu_group = None
+        # every rank must wait the same way: the gloo group is used only if ALL ranks got one
+        have = torch.tensor([1 if cpu_group is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if int(have.item()) == 0:
+            cpu_group = None
 
     def idle_barrier():
         if world > 1:
