@@ -521,6 +521,8 @@ struct HipBackend {
     HIP_CHECK(hipEventRecord(ev_wide_done, aux));
     wide_pending = true;
   }
+  // partitioned chip: the mark goes behind the head merge instead (MsmEngine::submit)
+  void merge_mark() { wide_mark(); }
   void wide_wait() {
     if (!wide_pending) return;
     HIP_CHECK(hipStreamWaitEvent(stream, ev_wide_done, 0));
@@ -533,29 +535,39 @@ struct HipBackend {
     tail_pending = false;
     wide_pending = false;   // (the end of the tail is behind its wide passes)
   }
-  static uint32_t quad_threshold() {
-    static const uint32_t v = getenv("CTT_HIP_MSM_QUAD") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_QUAD")) : 49152u;
-    // rounds 1-4: 24576 (measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768).  Round 5 swept it again with the
-    // small sizes in view (profiles/pyr_quad_threshold_r05.txt, same box, ms per MSM with two in flight at 24576 / 49152 / 131072):
-    // 2^16 0.443-0.454 / 0.439-0.450 / 0.436-0.448, 2^17 0.631 / 0.619 / 0.614, 2^18 0.978-0.993 / 0.974-0.986 / 0.965-0.989, 2^20 2.79-2.88 /
-    // 2.83-2.89 / 2.89-2.90 (blocking 3.13-3.17 / 3.14-3.16 / 3.23-3.25): 49152 takes the small sizes' 2 % and leaves 2^20 where it was
-    return v;
-  }
-  static bool pyr_is_narrow(uint32_t ntasks, uint32_t W) { return (uint64_t)ntasks * W <= quad_threshold(); }
-  // passes with at most this many additions (all windows) go to the tail stream
-  static bool pyr_goes_to_tail(uint32_t ntasks, uint32_t W) {
-    static const uint32_t v = getenv("CTT_HIP_MSM_TAIL") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_TAIL")) : 131072u;  // about what fits under the next MSM's conversion + sort (measured 2^20: 3.34 ms at 24576, 3.30 at 131072; above that the tail queues behind the next accumulation)
-    return (uint64_t)ntasks * W <= v;
-  }
+  // four lanes per addition below this many additions per pass (all windows).
+  // rounds 1-4: 24576 (measured at 2^20: 18 us vs 19.6 us at 18432 additions, 24 us vs 21 us at 32768).  Round 5 swept it again with the
+  // small sizes in view (profiles/pyr_quad_threshold_r05.txt, same box, ms per MSM with two in flight at 24576 / 49152 / 131072):
+  // 2^16 0.443-0.454 / 0.439-0.450 / 0.436-0.448, 2^17 0.631 / 0.619 / 0.614, 2^18 0.978-0.993 / 0.974-0.986 / 0.965-0.989, 2^20 2.79-2.88 /
+  // 2.83-2.89 / 2.89-2.90 (blocking 3.13-3.17 / 3.14-3.16 / 3.23-3.25): 49152 takes the small sizes' 2 % and leaves 2^20 where it was
+  uint32_t quad_adds = 49152u;       // $CTT_HIP_MSM_QUAD (read when the context is created)
+  // passes with at most this many additions (all windows) go to the tail stream: about what fits under the next MSM's conversion + sort
+  // (measured 2^20: 3.34 ms at 24576, 3.30 at 131072; above that the tail queues behind the next accumulation)
+  uint32_t tail_adds = 131072u;      // $CTT_HIP_MSM_TAIL
+  bool pyr_is_narrow(uint32_t ntasks, uint32_t W) const { return (uint64_t)ntasks * W <= quad_adds; }
+  bool pyr_goes_to_tail(uint32_t ntasks, uint32_t W) const { return (uint64_t)ntasks * W <= tail_adds; }
+  // ---- spatial partition of the chip (round 6): CU-masked streams ------------------------------------------------------------
+  // Every overlap of rounds 1-5 was temporal: the tail of MSM i (head merge, reduction passes, bit Horner, result copy) and the
+  // accumulation of MSM i+1 shared the SIMDs and instruction caches of every CU.  $CTT_HIP_CU_TAIL = r > 0 creates the tail stream with
+  // hipExtStreamCreateWithCUMask over r compute units of every XCD -- the low 8 r bits of the mask: the runtime deals the user mask
+  // round-robin over the XCDs (tools/cu_mask_probe.hip prints the placement) -- and, unless $CTT_HIP_CU_MAIN = 0, the main stream over
+  // the complement: the accumulate grid is then sized for the CUs it really has (resident_lanes), never waits for a tail and leaves no
+  // wave slots free on purpose.  Measured: profiles/cu_mask_r06.txt, DESIGN.md.
+  int cu_tail = 0;        // CUs per XCD in the tail stream's mask (0: an ordinary high-priority stream over the whole chip)
+  bool cu_main = false;   // the main stream is masked to the complement
+  static constexpr int XCDS = 8;
+  bool partitioned() const { return cu_tail > 0 && cu_main; }
+  int main_cus() const { return partitioned() ? num_cu - XCDS * cu_tail : num_cu; }
   int num_cu = 256;
   // stage events per in-flight slot; a host-pointer MSM runs the first stages once per upload slice (MsmEngine::submit_host):
   // every slice records its own pair (stage_chunk) and collect_timings adds them up
   static constexpr int MAX_CHUNKS = 8;
-  hipEvent_t ev_begin[2][ST_COUNT][MAX_CHUNKS], ev_end[2][ST_COUNT][MAX_CHUNKS];
-  uint32_t ev_used[2][ST_COUNT];   // bit i: chunk i recorded
+  static constexpr int NSLOT = 3;   // (= MsmEngine::NSLOT)
+  hipEvent_t ev_begin[NSLOT][ST_COUNT][MAX_CHUNKS] = {}, ev_end[NSLOT][ST_COUNT][MAX_CHUNKS] = {};
+  uint32_t ev_used[NSLOT][ST_COUNT];   // bit i: chunk i recorded
   int chunk = 0;
   void stage_chunk(int i) { chunk = i < MAX_CHUNKS ? i : MAX_CHUNKS - 1; }
-  hipEvent_t ev_done[2];
+  hipEvent_t ev_done[NSLOT] = {};
   float stage_ms[ST_COUNT];
 
   void init(int dev);  // msm_engine.hip
@@ -572,6 +584,15 @@ struct HipBackend {
     return p;
   }
   void free(void* p) { HIP_CHECK(hipFree(p)); }
+  // teardown paths (destructors, a context lost to a HIP failure): nothing to report to and nothing that may throw -- a failing hipFree
+  // on a context with a sticky error must not turn the documented recovery ("destroy it and create a new one") into std::terminate
+  void free_quiet(void* p) noexcept {
+    if (p && hipFree(p) != hipSuccess) (void)hipGetLastError();
+  }
+  void free_host_quiet(void* p) noexcept {
+    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+  }
+  void shutdown() noexcept;   // msm_engine.hip: streams and events of init()
   void memset0(void* p, size_t b) { HIP_CHECK(hipMemsetAsync(p, 0, b, stream)); }
   void d2d_async(void* dst, const void* src, size_t b) {
     HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToDevice, stream));
@@ -605,6 +626,14 @@ struct HipBackend {
   void uploader_begin() {
     HIP_CHECK(hipSetDevice(device));
     if (uploader_hook) uploader_hook(device);
+  }
+  // the helper thread that runs the host tails of pipelined MSMs (MsmEngine::tail_worker): it waits for result copies on this device
+  using GuardScope = ErrorGuard;
+  void tail_worker_begin() {
+    if (hipSetDevice(device) != hipSuccess) (void)hipGetLastError();   // (the first d2h_wait reports it)
+  }
+  [[noreturn]] void tail_worker_failed() {
+    hip_failed("host tail of a pipelined MSM (helper thread)", "the wait for the MSM's result copy failed", 0, __FILE__, __LINE__);
   }
   void h2d_slice_done(uint32_t i) { HIP_CHECK(hipEventRecord(ev_slice[i], cpy)); }
   void h2d_slice_wait(uint32_t i) { HIP_CHECK(hipStreamWaitEvent(stream, ev_slice[i], 0)); }
@@ -671,7 +700,7 @@ struct HipBackend {
     int nb = 0;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_accum<F, false>, ACCUM_BLOCK, 0));
     if (nb < 1) nb = 1;
-    return (uint32_t)nb * ACCUM_BLOCK * (uint32_t)num_cu;
+    return (uint32_t)nb * ACCUM_BLOCK * (uint32_t)main_cus();
   }
 
   static dim3 grid1(uint32_t n, int block) { return dim3((n + block - 1) / block); }
@@ -771,7 +800,7 @@ struct CurveOps {
   size_t aff_bytes;
   void* (*engine_create)(HipBackend* bk);
   void (*engine_destroy)(void* eng);
-  // split form: at most two MSMs in flight per engine; submit returns the slot (0/1), or -1 when both are taken;
+  // split form: at most MsmEngine::NSLOT (3) MSMs in flight per engine; submit returns the slot, or -1 when all are taken;
   // finish returns 0, or -1 when the slot is not in flight
   int (*submit)(void* eng, const MsmOptions* opt, const void* d_coefs, int coef_is_fr, const void* d_points, uint32_t n,
                 int* plan);

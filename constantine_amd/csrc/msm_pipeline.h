@@ -6,7 +6,10 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <functional>
+#include <mutex>
 #include <system_error>
 #include <thread>
 #include <type_traits>
@@ -74,6 +77,8 @@ struct MsmOptions {
   // BLS12-381 G1 2^16 0.466-0.473 / 0.480, 2^17 0.654-0.657 / 0.676-0.680, BN254 2^16 0.345 / 0.350 -- the fork's event pair costs what the
   // 25 us of overlap give (gpurun_out/r5i)
   int pyr0_tail = 0;
+  // host tail of an MSM kept in flight (MsmEngine::tail_worker): 0 automatic (a helper thread when the caller pipelines), 1 always, 2 never
+  int async_tail = 0;
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -392,21 +397,34 @@ struct MsmEngine {
 
   // grow-only workspace
   struct Buf { void* p = nullptr; size_t cap = 0; };
+  // In-flight slots.  Rounds 1-5 had two; round 6 read the timeline of a pipelined 2^16-pair loop (profiles/cu_mask_r06.txt): with two
+  // slots, submit(i+2) has to follow finish(i) -- the wait for MSM i's result copy, then its host tail (~0.1-0.2 ms: W c doublings on one
+  // core), then the enqueueing of ~24 launches -- and the main stream idles ~90 us of every 450 us step because MSM i+2's first kernel
+  // has not been enqueued yet when MSM i+1's main-stream chain ends.  With a third slot a caller submits MSM i+2 BEFORE it finishes MSM i.
+  static constexpr int NSLOT = 3;
   // bstartS / maxcountS / bucketsS: one per in-flight slot -- the head merge and the first reduction pass of MSM i read them on the tail
   // stream while the sort of MSM i+1 already writes its own (submit(): early tail)
-  Buf part, counts, bstartS[2], entries, bucketsS[2], heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcountS[2], cpoints, totals, gbase, mqueue;
+  Buf part, counts, bstartS[NSLOT], entries, bucketsS[NSLOT], heads, tails, hkey, tkey, rA[2], rP[2], scal, maxcountS[NSLOT], cpoints, totals, gbase, mqueue;
 
   explicit MsmEngine(BK& b) : bk(b) {}
   ~MsmEngine() {
-    Buf* all[] = {&part, &gbase, &counts, &bstartS[0], &bstartS[1], &entries, &bucketsS[0], &bucketsS[1], &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &maxcountS[0], &maxcountS[1], &cpoints, &totals, &mqueue};
-    for (Buf* b : all) if (b->p) bk.free(b->p);
-    for (Slot& sl : slots) if (sl.hraw) bk.free_host(sl.hraw);
+    tail_worker_stop();
+    Buf* all[] = {&part, &gbase, &counts, &entries, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &cpoints, &totals, &mqueue};
+    for (int i = 0; i < NSLOT; i++) {
+      bk.free_quiet(bstartS[i].p);
+      bk.free_quiet(bucketsS[i].p);
+      bk.free_quiet(maxcountS[i].p);
+    }
+    // (a destructor is noexcept: the quiet forms -- ctt_hip_msm_ctx_destroy of a context lost to a HIP failure comes through here)
+    for (Buf* b : all) if (b->p) bk.free_quiet(b->p);
+    for (Slot& sl : slots) if (sl.hraw) bk.free_host_quiet(sl.hraw);
   }
   void* need(Buf& b, size_t bytes) {
     if (bytes > b.cap) {
-      if (b.p) bk.free(b.p);
-      b.p = nullptr;
+      void* old = b.p;
+      b.p = nullptr;      // (before the free: if it throws, the destructor must not free the pointer a second time)
       b.cap = 0;
+      if (old) bk.free(old);
       size_t cap = bytes + bytes / 8 + 256;
       b.p = bk.alloc(cap);   // may throw OutOfDeviceMemory: the buffer is then simply empty
       b.cap = cap;
@@ -414,7 +432,7 @@ struct MsmEngine {
     return b.p;
   }
 
-  // Two MSMs may be in flight: submit() enqueues every kernel of one MSM plus the asynchronous copy of its
+  // Up to NSLOT MSMs may be in flight: submit() enqueues every kernel of one MSM plus the asynchronous copy of its
   // c points per window into a pinned host buffer; finish() waits for that copy and runs the host tail.
   // Calling submit(i+1) before finish(i) overlaps the host tail of MSM i with the GPU work of MSM i+1
   // (the workspace is shared: stream order keeps the two apart on the device).
@@ -425,9 +443,22 @@ struct MsmEngine {
     bool empty = false;   // len == 0
     void* hraw = nullptr; // pinned host buffer for the device output
     size_t hcap = 0;
+    // host tail on the helper thread (tail_worker): 0 the finishing thread runs it, 1 handed to the helper, 2 result ready, 3 the helper's wait failed
+    std::atomic<int> tail_state{0};
+    XYZZ<HF> tail_result;
   };
-  Slot slots[2];
+  Slot slots[NSLOT];
   int next_slot = 0;
+  int busy_count() const {
+    int k = 0;
+    for (const Slot& s : slots) k += s.busy ? 1 : 0;
+    return k;
+  }
+  // another MSM is in flight beside slot sl's: the caller is pipelining
+  bool other_busy(int sl) const {
+    for (int i = 0; i < NSLOT; i++) if (i != sl && slots[i].busy) return true;
+    return false;
+  }
 
   // d_coefs: canonical scalars [n][8] (coef_is_fr = false) or Montgomery Fr elements (true), device memory.
   // d_points: affine Montgomery points (reference representation), device memory.  Returns the slot.
@@ -605,7 +636,8 @@ struct MsmEngine {
     // slots up to 2^17 pairs, 1/64 of them while that costs less than half the wait), the previous tail's narrow passes run next to it, and the wait moves to the
     // start of this MSM's reduction (reduce_buckets), the first kernel that writes what the tail still reads.
     const uint64_t accum_waves = (uint64_t)W * ((p.G + 63u) / 64u);
-    if (accum_waves + tail_min_free_waves() > (uint64_t)opt.lanes / 64u) bk.tail_wait();
+    // (partitioned chip, HipBackend::partitioned: the tail stream has compute units of its own -- nothing to wait for, no slots to leave)
+    if (!bk.partitioned() && accum_waves + tail_min_free_waves() > (uint64_t)opt.lanes / 64u) bk.tail_wait();
     bk.wide_wait();   // (nothing to wait for unless the previous reduction put wide passes on the tail stream)
     bk.stage_begin(sl, ST_ACCUM);
     st.d_buckets = d_buckets;
@@ -671,7 +703,7 @@ struct MsmEngine {
     // orders the previous tail before this MSM's first write to the pyramid buffers).
     // (only for a caller that keeps MSMs in flight -- the other slot is busy: a lone blocking call would pay the fork's
     // event record and wait, ~15 us, for nothing)
-    const bool pipelining = slots[sl ^ 1].busy;
+    const bool pipelining = other_busy(sl);
     // wide_early: every pass but the first goes to the tail stream, the wide ones next to the following MSM's conversion and sort
     // (VALU-bound additions beside memory-bound kernels); that MSM's accumulation waits for the end of the WIDE passes only
     // (wide_mark / wide_wait) -- the narrow rest runs beside it in the wave slots its grid leaves free.
@@ -679,7 +711,7 @@ struct MsmEngine {
     // 10.75; no difference for the other curves -- the kernels do slow each other down (round 2 measured the sort 0.19 -> 0.23 ms
     // under wide passes), a quarter of the overlap is what remains.
     static const bool wide_early = !(getenv("CTT_HIP_MSM_WIDE_EARLY") && atoi(getenv("CTT_HIP_MSM_WIDE_EARLY")) == 0);
-    bool forked = forked_early, marked = false;
+    bool forked = forked_early, marked = forked_early && bk.partitioned();   // (partitioned: submit() marked behind the merge)
     const bool first_pass_on_tail = opt.pyr0_tail == 1 && p.n <= (1u << 17) && !p.merged;   // (MsmOptions::pyr0_tail: measured, off)
     for (int pass = 0; pass <= p.c - 2; pass++) {
       PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass, 1u};
@@ -730,10 +762,10 @@ struct MsmEngine {
 
   int claim_slot(uint32_t n) {
     int sl = next_slot;
-    if (slots[sl].busy) sl ^= 1;    // tickets may be finished in any order: take whichever slot is free
+    for (int k = 0; k < NSLOT && slots[sl].busy; k++) sl = (sl + 1) % NSLOT;    // tickets may be finished in any order: take whichever slot is free
     Slot& S = slots[sl];
-    if (S.busy) return -1;  // two MSMs in flight already: the caller finishes the oldest first (C ABI: error code)
-    next_slot = sl ^ 1;
+    if (S.busy) return -1;  // NSLOT MSMs in flight already: the caller finishes the oldest first (C ABI: error code)
+    next_slot = (sl + 1) % NSLOT;
     S.busy = true;
     S.empty = (n == 0);  // len == 0 is UB upstream; we return the neutral
     return sl;
@@ -755,11 +787,13 @@ struct MsmEngine {
     // G1 2^17, ms per MSM with two in flight: 0.69 with 17 % of the slots free, 0.80 with 5 %; since the larger sizes stopped waiting
     // for the tail too, 1/16 measures level or better: 2^17 0.742 against 0.759 ms with 5/32, G2 2^16 1.048 against 1.074.)
     // (the window size is chosen for the whole chip first: fewer lanes must only lengthen K)
-    if (slots[sl ^ 1].busy && n <= (1u << 17) && opt.K <= 0 && table_c <= 0) {
+    if (bk.partitioned()) {
+      // (the tail runs on compute units the accumulate grid never sees: opt.lanes counts the main stream's CUs only)
+    } else if (other_busy(sl) && n <= (1u << 17) && opt.K <= 0 && table_c <= 0) {
       if (po.c <= 0) po.c = choose_window_bits(n, C::BITS, opt.lanes, opt.acc_ns, opt.red_ns);
       static const uint32_t free32 = getenv("CTT_HIP_MSM_SMALL_FREE_32NDS") ? (uint32_t)atoi(getenv("CTT_HIP_MSM_SMALL_FREE_32NDS")) : 2u;
       po.lanes = (uint32_t)((uint64_t)opt.lanes * (32u - (free32 < 31u ? free32 : 31u)) / 32u);
-    } else if (slots[sl ^ 1].busy && opt.K <= 0 && table_c <= 0 && opt.lanes >= 64u * 1024u && opt.acc_ns >= 0.1) {
+    } else if (other_busy(sl) && opt.K <= 0 && table_c <= 0 && opt.lanes >= 64u * 1024u && opt.acc_ns >= 0.1) {
       // Larger ones: the accumulation used to wait for the previous tail -- ten dependent narrow passes, the bit Horner and the result
       // copy, ~0.25 ms after the last wide pass, 0.1 ms longer than this MSM's sort (rocprof timeline, BLS12-381 2^20: the sort ends
       // at 177 us, the accumulation started at 281).  With 1/64 of the wave slots left free (32 of 2048; K 128 -> 131 at 2^20) the
@@ -796,14 +830,20 @@ struct MsmEngine {
       // maxcountS, bucketsS); the next accumulation still waits for the end of the wide passes (wide_wait), so nothing of this tail
       // competes with an accumulation for wave slots (which is what sank round 3's version for small MSMs, section 5 of DESIGN.md).
       if (early_tail_applies(p)) {
-        bk.tail_wait();    // (the previous tail ended long ago: it ran beside this accumulation)
+        // (the previous tail ended long ago: it ran beside this accumulation.  Partitioned chip: it may still be crawling through its
+        // wide passes on its few compute units -- the tail stream is in order, and nothing on the main stream touches what it uses)
+        if (!bk.partitioned()) bk.tail_wait();
         bk.tail_begin();
       }
       merge_buckets(sl, p, st);
+      // Partitioned chip + early tail: the next accumulation shares the head / tail slots with this merge and nothing else with this
+      // tail -- it waits for the merge, not for the wide reduction passes (which run on the tail stream's own compute units)
+      if (bk.partitioned() && bk.tail_forked()) bk.merge_mark();
       reduce_buckets(sl, p, d_buckets);
     } catch (const OutOfDeviceMemory&) {
       return release_slot(sl);
     }
+    tail_handoff(sl);
     return sl;
   }
   // Only for a caller that is pipelining (the other slot is busy), from ~2^18 pairs on, and while the accumulation is shorter than ~6 ms.
@@ -814,7 +854,7 @@ struct MsmEngine {
   bool front_side_applies(const MsmPlan& p) const {
     static const int mode = getenv("CTT_HIP_MSM_FRONT") ? atoi(getenv("CTT_HIP_MSM_FRONT")) : 1;   // 0 off, 1 automatic, 2 whenever pipelining
     if (mode == 0 || opt.front_side == 2) return false;
-    if (!(slots[0].busy && slots[1].busy)) return false;    // a lone blocking call has nothing to run beside
+    if (busy_count() < 2) return false;    // a lone blocking call has nothing to run beside
     if (mode >= 2 || opt.front_side == 1) return true;
     // Measured and NOT adopted (profiles/front_stream_small_msm_r05.txt, same box, ms per MSM with two in flight, main stream only / front stream):
     // BLS12-381 G1 2^12 0.278 / 0.287, 2^14 0.388-0.393 / 0.383-0.386, 2^16 0.470 / 0.494, 2^17 0.637 / 0.664, G2 2^16 1.077 / 1.227.  The overlap
@@ -829,7 +869,7 @@ struct MsmEngine {
   bool early_tail_applies(const MsmPlan& p) const {
     static const int mode = getenv("CTT_HIP_MSM_EARLY_TAIL") ? atoi(getenv("CTT_HIP_MSM_EARLY_TAIL")) : 1;   // 0 off, 1 automatic, 2 whenever pipelining
     if (mode == 0 || opt.early_tail == 0) return false;
-    const bool pipelining = slots[0].busy && slots[1].busy;
+    const bool pipelining = busy_count() >= 2;
     if (!pipelining) return false;
     if (mode >= 2 || opt.early_tail >= 2) return true;
     const double additions = (double)p.nent * (double)p.W;
@@ -1061,19 +1101,14 @@ struct MsmEngine {
     } catch (const OutOfDeviceMemory&) {
       return release_slot(sl);
     }
+    tail_handoff(sl);
     return sl;
   }
   uint32_t last_chunks = 1;
 
   // Host tail of a submitted MSM: wait for its W window sums, Horner over the windows.
-  XYZZ<HF> finish(int sl) {
+  XYZZ<HF> host_tail(int sl) {
     Slot& S = slots[sl];
-    if (!S.busy) {
-      fprintf(stderr, "[ctt_msm] FATAL: finish() of a slot that was not submitted\n");
-      abort();
-    }
-    S.busy = false;
-    if (S.empty) return XYZZ<HF>::inf();
     bk.d2h_wait(sl);
     const MsmPlan& p = S.plan;
     const XYZZ<FD>* raw = (const XYZZ<FD>*)S.hraw;
@@ -1082,8 +1117,95 @@ struct MsmEngine {
     for (size_t i = 0; i < cnt; i++) sums[i] = xyzz_to_host<FD>(raw[i]);
     return combine_groups<HF>(sums.data(), p.W, p.lay, p.h, p.ngrp);
   }
+  // The host tail on a thread of its own (round 6).  A caller that keeps small MSMs in flight spends, per MSM, ~0.1 ms enqueueing the
+  // launches and 0.1-0.2 ms in the host tail (W c doublings, one core) -- 0.3 of a 0.45 ms step at 2^16 pairs, on ONE thread, with the
+  // next submit behind the previous finish.  The timeline (profiles/cu_mask_r06.txt) shows the main stream idle ~90 us per step waiting
+  // for launches that have not been enqueued yet.  With the tail handed to a helper at the end of submit(), the caller's finish() only
+  // collects the result, and its thread is free to enqueue.  Only for a caller that pipelines (another slot busy at submit time): a lone
+  // blocking call would pay two thread hand-offs for nothing.
+  std::thread tail_thread;
+  std::mutex tail_mu;
+  std::condition_variable tail_cv;
+  std::deque<int> tail_queue;
+  bool tail_stop = false;
+  void tail_worker() {
+    bk.tail_worker_begin();
+    for (;;) {
+      int sl;
+      {
+        std::unique_lock<std::mutex> lk(tail_mu);
+        tail_cv.wait(lk, [&]() { return tail_stop || !tail_queue.empty(); });
+        if (tail_queue.empty()) return;   // (stop)
+        sl = tail_queue.front();
+        tail_queue.pop_front();
+      }
+      Slot& S = slots[sl];
+      int done = 2;
+      try {
+        // (a failed HIP call on this thread must reach the caller of finish(), not abort the process: BK::guard_scope is the backend's
+        // "this thread can report" marker -- hip_errors.h ErrorGuard for the GPU, nothing for the emulator)
+        typename BK::GuardScope guard;
+        S.tail_result = host_tail(sl);
+      } catch (...) {
+        done = 3;
+      }
+      S.tail_state.store(done, std::memory_order_release);
+    }
+  }
+  void tail_worker_stop() {
+    if (!tail_thread.joinable()) return;
+    {
+      std::lock_guard<std::mutex> lk(tail_mu);
+      tail_stop = true;
+    }
+    tail_cv.notify_all();
+    tail_thread.join();
+  }
+  void tail_handoff(int sl) {
+    Slot& S = slots[sl];
+    S.tail_state.store(0, std::memory_order_relaxed);
+    if (S.empty || opt.async_tail == 2) return;
+    if (opt.async_tail != 1 && !other_busy(sl)) return;
+    if (!tail_thread.joinable()) {
+      try {
+        tail_thread = std::thread([this]() { tail_worker(); });
+      } catch (const std::system_error&) {
+        return;                           // (no thread to be had: the finishing thread runs the tail, as before)
+      }
+    }
+    S.tail_state.store(1, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> lk(tail_mu);
+      tail_queue.push_back(sl);
+    }
+    tail_cv.notify_one();
+  }
+  XYZZ<HF> finish(int sl) {
+    Slot& S = slots[sl];
+    if (!S.busy) {
+      fprintf(stderr, "[ctt_msm] FATAL: finish() of a slot that was not submitted\n");
+      abort();
+    }
+    if (S.empty) {
+      S.busy = false;
+      return XYZZ<HF>::inf();
+    }
+    if (S.tail_state.load(std::memory_order_acquire) == 0) {
+      const XYZZ<HF> r = host_tail(sl);    // (may throw through HIP_CHECK: the slot then stays claimed on a context that is lost anyway)
+      S.busy = false;
+      return r;
+    }
+    int st;
+    for (uint32_t spin = 0; (st = S.tail_state.load(std::memory_order_acquire)) == 1; spin++) {
+      if (spin < 4000u) cpu_relax(); else std::this_thread::yield();
+    }
+    S.tail_state.store(0, std::memory_order_relaxed);
+    S.busy = false;
+    if (st == 3) bk.tail_worker_failed();  // (throws or aborts like the HIP_CHECK that failed on the helper thread)
+    return S.tail_result;
+  }
 
-  bool in_flight(int sl) const { return sl >= 0 && sl < 2 && slots[sl].busy; }
+  bool in_flight(int sl) const { return sl >= 0 && sl < NSLOT && slots[sl].busy; }
 
   // r = sum of n affine points (sum_reduce_vartime, ec_shortweierstrass_batch_ops.nim:649-663).  One window, one
   // bucket: the identity entry list goes through the accumulate kernel (K points per lane) and the head-merging

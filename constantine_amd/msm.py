@@ -65,7 +65,7 @@ def multiScalarMul_vartime_parallel(tp, curve, coefs, points, coord="jac", fr_co
 
 
 class MsmRefused(RuntimeError):
-    """A neutral host-pointer symbol returned an error code: -1 refused (bad id / length / both slots busy), -2 out of device
+    """A neutral host-pointer symbol returned an error code: -1 refused (bad id / length / all slots busy), -2 out of device
     memory.  The caller that has a CPU implementation next to it (the Nim binding of INTEGRATION.md part B) falls back to it."""
 
     def __init__(self, code):
@@ -112,7 +112,7 @@ class DeviceMsm:
             self.ctx = None
 
     def set_option(self, key, value):
-        """ctt_hip_msm_set_option: "c", "K", "S", "chunks", "horner_bits", "host_window_sums", "sort_staged", "sort_xcd", "timings", "timings_every"
+        """ctt_hip_msm_set_option: "c", "K", "S", "chunks", "horner_bits", "host_window_sums", "sort_staged", "sort_xcd", "timings", "timings_every", "async_tail"
         (include/ctt_msm_hip.h); 0 = automatic / off.  KeyError for an unknown key."""
         if self.L.ctt_hip_msm_set_option(self.ctx, key.encode(), int(value)) != 0:
             raise KeyError(key)
@@ -149,13 +149,13 @@ class DeviceMsm:
         return r
 
     def submit(self, curve, d_coefs, d_points, n, fr_coefs=False):
-        """Enqueue one MSM and return a ticket at once (at most two outstanding per curve: a third raises)."""
+        """Enqueue one MSM and return a ticket at once (at most three outstanding per curve: a fourth raises)."""
         info = CURVES[curve]
         self._order(d_coefs, d_points)
         t = self.L.ctt_hip_msm_device_submit(self.ctx, info.cid, COEF_FR if fr_coefs else COEF_BIG,
                                              self._dptr(d_coefs), self._dptr(d_points), n)
         if t < 0:
-            raise RuntimeError("ctt_hip_msm_device_submit failed (bad arguments, or two tickets already outstanding)")
+            raise RuntimeError("ctt_hip_msm_device_submit failed (bad arguments, or three tickets already outstanding)")
         return (curve, t)
 
     def finish(self, ticket, coord="aff"):
@@ -309,7 +309,7 @@ class CachedBases:
 
     def submit(self, d_coefs, n, fr_coefs=False):
         """Coefficients resident on the device (torch CUDA tensor or raw address): enqueue and return a ticket for
-        DeviceMsm.finish / CachedBases.finish (at most two outstanding per curve)."""
+        DeviceMsm.finish / CachedBases.finish (at most three outstanding per curve)."""
         if n > self.n:
             raise AssertionError("more coefficients than cached bases")
         if hasattr(d_coefs, "data_ptr") and getattr(d_coefs, "is_cuda", False):
@@ -319,7 +319,7 @@ class CachedBases:
         t = self.L.ctt_hip_msm_with_bases_submit(self.ctx, self.handle, COEF_FR if fr_coefs else COEF_BIG,
                                                  DeviceMsm._dptr(d_coefs), n)
         if t < 0:
-            raise RuntimeError("ctt_hip_msm_with_bases_submit failed (wrong context, or two tickets already outstanding)")
+            raise RuntimeError("ctt_hip_msm_with_bases_submit failed (wrong context, or three tickets already outstanding)")
         return (self.curve, t)
 
     def finish(self, ticket, coord="prj"):

@@ -144,7 +144,7 @@ CTT_BATCH_AFFINE_DECL(vesta_ec_prj, vesta_ec_aff)
  *
  * Why a call was refused -- per thread, set by every symbol of this header that returns an error value (NULL, -1, -2, or Part 3's
  * CTT_HIP_STATUS_GPU_UNAVAILABLE); a successful call leaves it alone:
- *    0 none   -1 refused (bad arguments; both in-flight slots of the context taken)   -2 out of device memory
+ *    0 none   -1 refused (bad arguments; all in-flight slots of the context taken)   -2 out of device memory
  *   -3 no usable HIP device   -4 a HIP runtime call failed: the context it happened on is LOST -- every later call on it is
  *      refused with -4; destroy it and create a new one (the default context of the host-pointer symbols stays lost) */
 int ctt_hip_last_error(void);
@@ -182,18 +182,23 @@ void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
  * "horner_bits" bits per group of the bit Horner the device runs per window (0 = 4; the host joins the groups),
  * "host_window_sums" (legacy spelling: 1 = groups of one bit, 2 = one group per window), "timings" 1 = record the
  * stage events ctt_hip_msm_last_timings reads (2 = the accumulate stage and the total only), "timings_every" k = only every
- * k-th MSM records them (the others report zeros; default 1).  value 0 = automatic /
- * off.  Returns 0, or -1 for an unknown key. */
+ * k-th MSM records them (the others report zeros; default 1), "async_tail" the host tail of an MSM submitted while another is
+ * outstanding runs on a helper thread of the context (0 automatic = yes, 1 also for lone calls, 2 never: the finishing thread runs it).
+ * value 0 = automatic / off.  Returns 0, or -1 for an unknown key.
+ * A context created with $CTT_HIP_CU_TAIL = r > 0 partitions the chip: its tail stream runs on r compute units of every XCD
+ * (hipExtStreamCreateWithCUMask), its main stream on the others -- an experiment of round 6, measured slower than sharing the chip
+ * (profiles/cu_mask_r06.txt); such streams are BLOCKING streams: do not order them behind the legacy null stream. */
 int ctt_hip_msm_set_option(ctt_hip_msm_ctx* ctx, const char* key, int value);
 /* r (HOST memory, `out_kind` layout) = sum coefs[i] * points[i]; d_coefs / d_points are DEVICE pointers
  * (BigInt canonical or Fr Montgomery 32-byte scalars; affine Montgomery points, C-API struct layout).
- * Returns 0; -1 for a bad curve id, len > 2^31-1, or two tickets outstanding on the curve.  Blocks until r is written. */
+ * Returns 0; -1 for a bad curve id, len > 2^31-1, or three tickets outstanding on the curve.  Blocks until r is written. */
 int ctt_hip_msm_device(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, int out_kind, void* r, const void* d_coefs,
                        const void* d_points, size_t len);
 /* Split form: submit enqueues the GPU work of one MSM and returns a ticket (>= 0) at once, or -1 on bad arguments or
- * when two tickets are outstanding on the curve; finish waits for the ticket, runs the host tail (Horner over windows,
- * affine normalisation) and writes r (0, or -1 for a ticket that is not outstanding).  Submitting MSM i+1 before
- * finishing MSM i overlaps the host tail of i with the GPU work of i+1 (how bench.py keeps the GPU busy). */
+ * when three tickets are outstanding on the curve (two in rounds 1-5); finish waits for the ticket, runs the host tail (Horner over
+ * windows, affine normalisation) and writes r (0, or -1 for a ticket that is not outstanding).  Submitting MSM i+1 before
+ * finishing MSM i overlaps the host tail of i with the GPU work of i+1 (how bench.py keeps the GPU busy); a caller of SMALL MSMs
+ * (up to ~2^18 pairs: the host tail and the enqueueing are a third of a step there) keeps three outstanding -- submit i+2, then finish i. */
 int ctt_hip_msm_device_submit(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, const void* d_coefs, const void* d_points,
                               size_t len);
 int ctt_hip_msm_device_finish(ctt_hip_msm_ctx* ctx, int ticket, int out_kind, void* r);

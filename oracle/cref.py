@@ -101,7 +101,7 @@ def scalar_mul(curve: str, k: np.ndarray, p: np.ndarray) -> np.ndarray:
 
 def gen_points_unknown_log(curve: str, seed: int, n: int, first: int = 0, nthreads: int = 0) -> np.ndarray:
     """Random points of the prime-order subgroup with UNKNOWN discrete logarithms (random x, square root, cofactor clearing: the
-    reference's bench inputs, msm_ref.cpp gen_points_unknown_log); bls12_381_g1 and bn254_snarks_g1."""
+    reference's bench inputs, msm_ref.cpp gen_points_unknown_log); all six curves of the path."""
     out = np.zeros((n, AFF_BYTES[curve]), dtype=np.uint8)
     nt = nthreads or (os.cpu_count() or 1)
     assert lib().oracle_gen_points_unknown_log(CURVE_ID[curve], seed & (2**64 - 1), first, n, _ptr(out), nt) == 0

@@ -890,47 +890,155 @@ template <class F> static Aff<F> aff_from_u64(u64 x, u64 y) { return {F::from_u6
 
 // Random curve points with UNKNOWN discrete logarithms, the way the reference's benches make their inputs
 // (helpers/prng_unsafe.nim:306-316 random_unsafe(ECP) -> trySetFromCoordX; benchmarks/bench_elliptic_parallel_template.nim:78-102 then
-// clears the cofactor): x from a 2x-width uniform integer reduced mod p, accepted when x^3 + b is a square, y = the root
-// (x^3 + b)^((p+1)/4) (p = 3 mod 4 for BLS12-381 and BN254-Snarks), then [h] (x, y).  The stream is this file's splitmix64, not the
-// reference's xoshiro: what matters to the tests built on it is that nobody knows log_G of these points -- the synthetic inputs
-// [s_i]G of gen_points let a test compute the MSM as one scalar multiplication; these do not.
-template <class F>
-static void gen_points_unknown_log(u64 b_small, const u64* cofactor, int cof_limbs, u64 seed, size_t first, size_t n, void* out, int nthreads) {
-  Aff<F>* o = (Aff<F>*)out;
-  constexpr int N = F::N;
-  // (p + 1) / 4
-  u64 e[N];
-  {
-    u64 one[N] = {1}, t[N];
-    add_n<N>(t, F::ctx.p, one);       // p + 1 does not overflow: the moduli have spare bits
-    for (int i = 0; i < N; i++) e[i] = (t[i] >> 2) | (i + 1 < N ? t[i + 1] << 62 : 0);
+// clears the cofactor): x from a 2x-width uniform integer reduced mod p (every coordinate of x over Fp2), accepted when x^3 + b is a
+// square, y = a square root, then [h] (x, y).  The stream is this file's splitmix64, not the reference's xoshiro: what matters to the
+// tests built on it is that nobody knows log_G of these points -- the synthetic inputs [s_i]G of gen_points let a test compute the
+// MSM as one scalar multiplication; these do not.
+// Square roots: p = 3 mod 4 (BLS12-381, BN254-Snarks) a^((p+1)/4) (the reference: sqrt_p3mod4, finite_fields_square_root.nim);
+// the Pasta primes have p - 1 = 2^32 t: Tonelli-Shanks (the reference's default for them, sqrt_tonelli_shanks);
+// Fp2 = Fp[i]/(i^2+1) by the complex method over the base field's root (the reference: sqrt_if_square for QuadraticExt).
+template <class B>
+static B fp_pow(const B& a, const u64* e, int nl) {
+  B r = B::one();
+  for (int i = nl * 64 - 1; i >= 0; i--) {
+    r = B::sqr(r);
+    if ((e[i / 64] >> (i % 64)) & 1) r = B::mul(r, a);
   }
-  const F b = F::from_u64(b_small);
-  // R mod p as a field element times x_hi gives the 2x-width reduction: x = (hi * 2^(64 N) + lo) mod p
+  return r;
+}
+template <class B>
+struct SqrtCtx {
+  static constexpr int N = B::N;
+  bool p3mod4;
+  u64 e34[N];      // (p + 1) / 4
+  int S;           // p - 1 = 2^S T, T odd
+  u64 T[N], Th[N]; // T, (T + 1) / 2
+  B c;             // z^T for a non-residue z
+  SqrtCtx() {
+    const u64* P = B::ctx.p;
+    p3mod4 = (P[0] & 3) == 3;
+    u64 one[N] = {1}, t[N];
+    add_n<N>(t, P, one);   // p + 1 does not overflow: the moduli have spare bits
+    for (int i = 0; i < N; i++) e34[i] = (t[i] >> 2) | (i + 1 < N ? t[i + 1] << 62 : 0);
+    u64 pm1[N];
+    memcpy(pm1, P, sizeof pm1);
+    pm1[0] -= 1;
+    S = 0;
+    memcpy(T, pm1, sizeof T);
+    while (!(T[0] & 1)) {
+      for (int i = 0; i < N; i++) T[i] = (T[i] >> 1) | (i + 1 < N ? T[i + 1] << 63 : 0);
+      S++;
+    }
+    add_n<N>(t, T, one);
+    for (int i = 0; i < N; i++) Th[i] = (t[i] >> 1) | (i + 1 < N ? t[i + 1] << 63 : 0);
+    u64 half[N];                                        // (p - 1) / 2: Euler's criterion
+    for (int i = 0; i < N; i++) half[i] = (pm1[i] >> 1) | (i + 1 < N ? pm1[i + 1] << 63 : 0);
+    const B minus1 = B::neg(B::one());
+    for (u64 z = 2;; z++) {
+      const B zz = B::from_u64(z);
+      if (fp_pow<B>(zz, half, N) == minus1) { c = fp_pow<B>(zz, T, N); break; }
+    }
+  }
+  static const SqrtCtx& get() { static const SqrtCtx k; return k; }
+};
+template <class B>
+static bool f_sqrt(const B& a, B& r) {
+  const SqrtCtx<B>& K = SqrtCtx<B>::get();
+  if (a.is_zero()) { r = a; return true; }
+  if (K.p3mod4) {
+    r = fp_pow<B>(a, K.e34, B::N);
+    return B::sqr(r) == a;
+  }
+  B x = fp_pow<B>(a, K.Th, B::N), t = fp_pow<B>(a, K.T, B::N), c = K.c;
+  int m = K.S;
+  const B one = B::one();
+  while (!(t == one)) {
+    int i = 0;
+    B tt = t;
+    while (!(tt == one)) { tt = B::sqr(tt); i++; if (i == m) return false; }   // not a square
+    B b = c;
+    for (int k = 0; k < m - i - 1; k++) b = B::sqr(b);
+    x = B::mul(x, b);
+    c = B::sqr(b);
+    t = B::mul(t, c);
+    m = i;
+  }
+  r = x;
+  return B::sqr(r) == a;
+}
+template <class B>
+static bool f_sqrt(const Fp2<B>& a, Fp2<B>& r) {
+  if (a.c1.is_zero()) {
+    B s;
+    if (f_sqrt<B>(a.c0, s)) { r = {s, B::zero()}; return true; }
+    if (f_sqrt<B>(B::neg(a.c0), s)) { r = {B::zero(), s}; return true; }   // i^2 = -1
+    return false;
+  }
+  B s;
+  if (!f_sqrt<B>(B::add(B::sqr(a.c0), B::sqr(a.c1)), s)) return false;      // the norm of a square is a square
+  const B inv2 = B::inv(B::from_u64(2));
+  for (int k = 0; k < 2; k++) {
+    const B d = B::mul(k == 0 ? B::add(a.c0, s) : B::sub(a.c0, s), inv2);
+    B x0;
+    if (!f_sqrt<B>(d, x0) || x0.is_zero()) continue;
+    const B x1 = B::mul(a.c1, B::inv(B::dbl(x0)));
+    const Fp2<B> cand{x0, x1};
+    if (Fp2<B>::sqr(cand) == a) { r = cand; return true; }
+  }
+  return false;
+}
+// one coordinate from a 2x-width uniform integer: (hi * 2^(64 N) + lo) mod p
+template <class B>
+static B draw_fp(u64 key, u64& ctr) {
+  constexpr int N = B::N;
+  B xl, xh;
+  for (int q = 0; q < N; q++) xl.l[q] = splitmix64(key + ctr++);
+  for (int q = 0; q < N; q++) xh.l[q] = splitmix64(key + ctr++);
+  while (geq_n<N>(xl.l, B::ctx.p)) sub_n<N>(xl.l, xl.l, B::ctx.p);
+  while (geq_n<N>(xh.l, B::ctx.p)) sub_n<N>(xh.l, xh.l, B::ctx.p);
+  // to_mont(lo) = lo R, to_mont(hi) = hi R; x R = lo R + mont_mul(hi R, R^2) (to_mont(one()) = R^2 as a residue)
+  return B::add(B::to_mont(xl), B::mul(B::to_mont(xh), B::to_mont(B::one())));
+}
+template <class B> static void draw_x(B& x, u64 key, u64& ctr) { x = draw_fp<B>(key, ctr); }
+template <class B> static void draw_x(Fp2<B>& x, u64 key, u64& ctr) { x.c0 = draw_fp<B>(key, ctr); x.c1 = draw_fp<B>(key, ctr); }
+
+// [k]P, k = cof_limbs little-endian words, plain double-and-add
+template <class F>
+static Jac<F> mul_words(const Aff<F>& P, const u64* k, int limbs) {
+  Jac<F> r = Jac<F>::inf();
+  for (int bit = 64 * limbs - 1; bit >= 0; bit--) {
+    r = Jac<F>::dbl(r);
+    if ((k[bit / 64] >> (bit % 64)) & 1) r = Jac<F>::madd(r, P, false);
+  }
+  return r;
+}
+template <class F>
+static Jac<F> mul_words(const Jac<F>& P, const u64* k, int limbs) {
+  Jac<F> r = Jac<F>::inf();
+  for (int bit = 64 * limbs - 1; bit >= 0; bit--) {
+    r = Jac<F>::dbl(r);
+    if ((k[bit / 64] >> (bit % 64)) & 1) r = Jac<F>::add(r, P);
+  }
+  return r;
+}
+template <class F> static Jac<F> jac_neg(const Jac<F>& p) { return {p.x, F::neg(p.y), p.z}; }
+
+// clear: (x, y) on the curve -> a point of the prime-order subgroup (Jacobian)
+template <class F, class Clear>
+static void gen_points_unknown_log(const F& b, Clear clear, u64 seed, size_t first, size_t n, void* out, int nthreads) {
+  Aff<F>* o = (Aff<F>*)out;
   auto work = [&](size_t lo_i, size_t hi_i) {
     for (size_t i = lo_i; i < hi_i; i++) {
-      for (u64 attempt = 0;; attempt++) {
-        u64 w[2 * N];
-        for (int q = 0; q < 2 * N; q++) w[q] = splitmix64(seed * 0x9E3779B97F4A7C15ull + (first + i) * 64 + attempt * 2 * N + q);
-        // reduce: to_mont(lo) and to_mont(hi) are lo R and hi R; x R = lo R + (hi R)(R R)/R ... = lo R + mont_mul(hi R, R^2 R / R)
-        F xl, xh;
-        for (int q = 0; q < N; q++) { xl.l[q] = w[q]; xh.l[q] = w[N + q]; }
-        while (geq_n<N>(xl.l, F::ctx.p)) sub_n<N>(xl.l, xl.l, F::ctx.p);
-        while (geq_n<N>(xh.l, F::ctx.p)) sub_n<N>(xh.l, xh.l, F::ctx.p);
-        const F X = F::add(F::to_mont(xl), F::mul(F::to_mont(xh), F::to_mont(F::one())));   // lo + hi * 2^(64 N)  (mod p)
+      const u64 key = seed * 0x9E3779B97F4A7C15ull + (first + i) * 4096;
+      u64 ctr = 0;
+      for (;;) {
+        F X;
+        draw_x(X, key, ctr);
         const F rhs = F::add(F::mul(F::sqr(X), X), b);
-        F y = F::one();
-        for (int bit = 64 * N - 1; bit >= 0; bit--) {
-          y = F::sqr(y);
-          if ((e[bit / 64] >> (bit % 64)) & 1) y = F::mul(y, rhs);
-        }
-        if (!(F::sqr(y) == rhs)) continue;          // not a square: next candidate
+        F y;
+        if (!f_sqrt(rhs, y)) continue;              // not a square: next candidate
         const Aff<F> P{X, y};
-        Jac<F> r = Jac<F>::inf();
-        for (int bit = 64 * cof_limbs - 1; bit >= 0; bit--) {
-          r = Jac<F>::dbl(r);
-          if ((cofactor[bit / 64] >> (bit % 64)) & 1) r = Jac<F>::madd(r, P, false);
-        }
+        const Jac<F> r = clear(P);
         if (r.is_inf()) continue;                   // (a point of the cofactor's torsion: next candidate)
         o[i] = r.to_aff();
         break;
@@ -1057,6 +1165,14 @@ static const EndoG2Table& endo_g2_table() {
 template <> struct EndoG2For<Fp2<BlsFp>> { static const EndoG2* get(int c) { return c == C_BLS_G2 ? &endo_g2_table().bls : nullptr; } static const PsiCoef<Fp2<BlsFp>>& psi_coef(int) { return endo_g2_table().psi_bls; } };
 template <> struct EndoG2For<Fp2<BnFp>> { static const EndoG2* get(int c) { return c == C_BN_G2 ? &endo_g2_table().bn : nullptr; } static const PsiCoef<Fp2<BnFp>>& psi_coef(int) { return endo_g2_table().psi_bn; } };
 
+// psi on Jacobian coordinates: x = X / Z^2, y = Y / Z^3 and psi(x, y) = (conj(x) c2, conj(y) c3) give (conj(X) c2, conj(Y) c3, conj(Z))
+template <class F2>
+static Jac<F2> psi_jac(const PsiCoef<F2>& C, const Jac<F2>& p) {
+  if (p.is_inf()) return p;
+  auto conj = [](const F2& a) { return F2{a.c0, decltype(a.c0)::neg(a.c1)}; };
+  return {F2::mul(conj(p.x), C.c2), F2::mul(conj(p.y), C.c3), conj(p.z)};
+}
+
 extern "C" {
 
 // returns the window size c used (>0), or <0 on bad curve id. out = affine point in the C-API layout
@@ -1148,16 +1264,46 @@ int oracle_scalar_mul(int curve, const void* k, const void* p, void* out) {
 int oracle_best_bucket_bit_size(size_t n, int bits) { return best_bucket_bit_size(n, bits, true, true); }
 
 // out[i], i in [first, first + n): random points of the prime-order subgroup whose discrete logarithms nobody knows
-// (gen_points_unknown_log); BLS12-381 G1 (cofactor 0x396c8c005555e1568c00aaab0000aaab) and BN254-Snarks G1 (cofactor 1)
+// (gen_points_unknown_log), every curve of the path.  Cofactor clearing -- the reference has both forms (clearCofactorReference: the
+// multiplication by the cofactor; clearCofactorFast, zoo_subgroups.nim:34-40 -> bls12_381_subgroups.nim / bn254_snarks_subgroups.nim:
+// the endomorphism-accelerated maps); this port takes the cheap one where the cofactor is long:
+//   BLS12-381 G1   [1 - x]P, x = -0xd201000000010000 (64 bits, weight 6) instead of the 126-bit cofactor (Wahby-Boneh; the reference's fast form)
+//   BLS12-381 G2   [x^2 - x - 1]P + [x - 1]psi(P) + psi^2([2]P) (Budroni-Pintore; the reference's fast form) instead of 512 bits
+//   BN254-Snarks G2  the multiplication by #E'(Fp2) / r = 2p - r (256 bits)
+//   BN254-Snarks G1, Pallas, Vesta: prime order, nothing to clear.
+// tests/test_oracle_c.py holds samples of every curve to the big-integer oracle: on the curve, distinct, [r]P neutral.
 int oracle_gen_points_unknown_log(int curve, u64 seed, size_t first, size_t n, void* out, int nthreads) {
   ensure_init();
+  static const u64 absx[1] = {0xd201000000010000ull};   // |x| of BLS12-381; x < 0
   switch (curve) {
     case C_BLS_G1: {
-      static const u64 h[2] = {0x8c00aaab0000aaabull, 0x396c8c005555e156ull};
-      gen_points_unknown_log<BlsFp>(4, h, 2, seed, first, n, out, nthreads); return 0; }
-    case C_BN_G1: {
-      static const u64 h[1] = {1};
-      gen_points_unknown_log<BnFp>(3, h, 1, seed, first, n, out, nthreads); return 0; }
+      static const u64 h[1] = {0xd201000000010001ull};  // 1 - x
+      gen_points_unknown_log<BlsFp>(BlsFp::from_u64(4), [](const Aff<BlsFp>& P) { return mul_words<BlsFp>(P, h, 1); }, seed, first, n, out, nthreads);
+      return 0; }
+    case C_BN_G1: gen_points_unknown_log<BnFp>(BnFp::from_u64(3), [](const Aff<BnFp>& P) { return Jac<BnFp>::from_aff(P); }, seed, first, n, out, nthreads); return 0;
+    case C_PALLAS: gen_points_unknown_log<PallasFp>(PallasFp::from_u64(5), [](const Aff<PallasFp>& P) { return Jac<PallasFp>::from_aff(P); }, seed, first, n, out, nthreads); return 0;
+    case C_VESTA: gen_points_unknown_log<VestaFp>(VestaFp::from_u64(5), [](const Aff<VestaFp>& P) { return Jac<VestaFp>::from_aff(P); }, seed, first, n, out, nthreads); return 0;
+    case C_BLS_G2: {   // y^2 = x^3 + 4 (1 + i), M-twist (config_fields_and_curves.nim:269-287)
+      using F2 = Fp2<BlsFp>;
+      const F2 b{BlsFp::from_u64(4), BlsFp::from_u64(4)};
+      const PsiCoef<F2>& K = endo_g2_table().psi_bls;
+      auto clear = [&K](const Aff<F2>& P) {
+        const Jac<F2> Pj = Jac<F2>::from_aff(P);
+        const Jac<F2> t1 = jac_neg(mul_words<F2>(P, absx, 1));        // [x]P
+        const Jac<F2> t2 = jac_neg(mul_words<F2>(t1, absx, 1));       // [x^2]P
+        const Jac<F2> t1mP = Jac<F2>::add(t1, jac_neg(Pj));           // [x - 1]P
+        Jac<F2> r = Jac<F2>::add(t2, jac_neg(t1));                    // [x^2 - x]P
+        r = Jac<F2>::add(r, jac_neg(Pj));                             // [x^2 - x - 1]P
+        r = Jac<F2>::add(r, psi_jac<F2>(K, t1mP));                    // + psi([x - 1]P)
+        return Jac<F2>::add(r, psi_jac<F2>(K, psi_jac<F2>(K, Jac<F2>::dbl(Pj))));   // + psi^2([2]P)
+      };
+      gen_points_unknown_log<F2>(b, clear, seed, first, n, out, nthreads); return 0; }
+    case C_BN_G2: {    // y^2 = x^3 + 3 / (9 + i), D-twist (config_fields_and_curves.nim:116-133); cofactor 2p - r
+      using F2 = Fp2<BnFp>;
+      static const u64 h[4] = {0x345f2299c0f9fa8dull, 0x06ceecda572a2489ull, 0xb85045b68181585eull, 0x30644e72e131a029ull};
+      const F2 xi{BnFp::from_u64(9), BnFp::from_u64(1)};
+      const F2 b = F2::mul(F2{BnFp::from_u64(3), BnFp::zero()}, F2::inv(xi));
+      gen_points_unknown_log<F2>(b, [](const Aff<F2>& P) { return mul_words<F2>(P, h, 4); }, seed, first, n, out, nthreads); return 0; }
   }
   return -1;
 }

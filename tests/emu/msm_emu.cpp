@@ -20,6 +20,10 @@ struct EmuBackend {
     return malloc(b);
   }
   void free(void* p) { ::free(p); }
+  void free_quiet(void* p) noexcept { ::free(p); }
+  void free_host_quiet(void* p) noexcept { ::free(p); }
+  static bool partitioned() { return false; }
+  void merge_mark() {}
   void memset0(void* p, size_t b) { memset(p, 0, b); }
   void d2d_async(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
   void* alloc_host(size_t b) { return malloc(b); }
@@ -41,6 +45,9 @@ struct EmuBackend {
   void h2d_done() {}
   static constexpr bool THREADED_UPLOAD = true;   // (the slices of submit_host are copied by a thread here too: same code path)
   void uploader_begin() {}
+  struct GuardScope {};
+  void tail_worker_begin() {}
+  [[noreturn]] void tail_worker_failed() { abort(); }
   void h2d_slice_done(uint32_t) {}
   void h2d_slice_wait(uint32_t) {}
   void h2d_coefs_done(uint32_t) {}
@@ -357,8 +364,11 @@ struct EmuCurve {
     if (c < 0) refused++; else write_result<HF>((char*)r3 + 2 * ab, eng.finish(c), OUT_AFF);
     const int d = eng.submit((const uint32_t*)coefs, false, (const Affine<F>*)points, (uint32_t)n);
     const int e = d >= 0 ? eng.submit((const uint32_t*)coefs, false, (const Affine<F>*)points, (uint32_t)n) : -1;
+    const int f = e >= 0 ? eng.submit((const uint32_t*)coefs, false, (const Affine<F>*)points, (uint32_t)n) : -1;
     if (d < 0) refused++;
-    if (e >= 0) refused += 10;   // A and D are outstanding: a third ticket must be refused
+    if (e < 0) refused++;        // three slots (MsmEngine::NSLOT): A, D and E may be outstanding together
+    if (f >= 0) refused += 10;   // ... and a fourth ticket must be refused
+    if (e >= 0) eng.finish(e);   // (out of submission order: tickets may be finished in any order)
     if (d >= 0) eng.finish(d);
     write_result<HF>(r3, eng.finish(a), OUT_AFF);
     return refused;

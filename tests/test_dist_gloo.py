@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the point-sharded MSM (constantine_amd/parallel.py) on CPU.
+"""world_size-2 / 3 / 8 gloo tests of the point-sharded MSM (constantine_amd/parallel.py) on CPU.
 There is no GPU in this container, so every rank's partial MSM is computed by tests/emu -- the CPU emulator that runs the
 engine's own kernel bodies and host orchestration (msm_bodies.h, msm_pipeline.h) -- and the sharding, the all_gather
 exchange and the host-side combine (product code, ctt_hip_ec_sum_affine) run as they do on the GPUs.  The oracle only
@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, n, q):
+def _worker(rank, world, port, name, n, steps, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from constantine_amd import parallel
@@ -42,7 +42,7 @@ def _worker(rank, world, port, name, n, q):
         # step k multiplies by k + 1 through the scalars' low word so that a stale buffer would show
         x = parallel.ShardExchange(name)
         outs, prev = [], None
-        for k in range(3):
+        for k in range(steps):
             sck = sc.copy()
             sck[:, 0] = (k * 37 + 1) & 0xFF
             h = x.start(emu.msm(name, sck, pts, out_kind=0)[0])
@@ -55,38 +55,51 @@ def _worker(rank, world, port, name, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,n", [("bls12_381_g1", 101), ("bn254_snarks_g1", 64)])
-def test_sharded_msm_two_ranks(name, n):
+# world sizes 2, 3 and 8 (the node the metric is quoted on); n not divisible by the world size (uneven remainders of
+# balancedChunksPrioNumber, partitioners.nim:44-77), n < world size (ranks with an EMPTY shard contribute the neutral element), and
+# the pipelined exchange over >= 4 steps (both buffer sets reused at least once)
+@pytest.mark.parametrize("name,n,world,steps", [
+    ("bls12_381_g1", 101, 2, 3), ("bn254_snarks_g1", 64, 2, 3),
+    ("bls12_381_g1", 100, 3, 4),
+    ("bls12_381_g1", 203, 8, 5),
+    ("bn254_snarks_g1", 5, 8, 4),       # five ranks hold one pair each, three ranks none
+    ("bls12_381_g2", 37, 8, 4),
+])
+def test_sharded_msm_over_gloo_ranks(name, n, world, steps):
     from oracle import cref
     from tests.emu import emu
-    emu.lib()                       # built here, before the ranks start (they would otherwise both run `make`)
+    emu.lib()                       # built here, before the ranks start (they would otherwise all run `make`)
+    cref.lib()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, n, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=300) for _ in range(2)]
+    got = [q.get(timeout=600) for _ in range(world)]
     out = {r: a for r, a, _ in got}
     piped = {r: b for r, _, b in got}
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
+    assert sorted(out) == list(range(world))
     bits = 254 if "bn254" in name else 255
     pts = cref.gen_points(name, 77, n)
     sc = cref.synth_scalars(78, n, bits)
     expect, _ = cref.msm(name, sc, pts)
-    assert out[0] == out[1] == bytes(expect)
-    for k in range(3):
+    for r in range(world):
+        assert out[r] == bytes(expect), r
+    for k in range(steps):
         sck = sc.copy()
         sck[:, 0] = (k * 37 + 1) & 0xFF
         expect, _ = cref.msm(name, sck, pts)
-        assert piped[0][k] == piped[1][k] == bytes(expect), k
+        for r in range(world):
+            assert piped[r][k] == bytes(expect), (r, k)
 
 
 def test_shard_bounds_balanced():
     from constantine_amd.parallel import shard_bounds
-    for n, w in ((40, 12), (7, 8), (1 << 24, 8), (5, 2)):
+    for n, w in ((40, 12), (7, 8), (1 << 24, 8), (5, 2), (0, 8), (1, 8), (203, 8), ((1 << 20) + 3, 3)):
         spans = [shard_bounds(n, w, r) for r in range(w)]
         assert spans[0][0] == 0 and sum(l for _, l in spans) == n
         for (s0, l0), (s1, _) in zip(spans, spans[1:]):

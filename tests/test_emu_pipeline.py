@@ -377,8 +377,9 @@ def test_horner_groups(monkeypatch):
 
 
 def test_tickets_finished_out_of_order():
-    """Two slots per engine: with ticket A outstanding, blocking calls B and C must both be served (the free slot is
-    taken whichever it is), a third outstanding ticket is refused, and A still finishes correctly afterwards."""
+    """Three slots per engine (round 6; two before): with ticket A outstanding, blocking calls B and C must both be served (a free
+    slot is taken whichever it is), three tickets may be outstanding together, a fourth is refused, and A still finishes correctly
+    afterwards."""
     name = "bls12_381_g1"
     n = 90
     pts = cref.gen_points(name, 911, n)

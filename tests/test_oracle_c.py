@@ -203,3 +203,27 @@ def test_bug366_regression_on_its_real_input():
     assert curve.aff_from_bytes(bytes(out)) == want
     out, _ = cref.msm("bn254_snarks_g2", sc, pts, nthreads=8)
     assert curve.aff_from_bytes(bytes(out)) == want
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_points_with_unknown_logs_are_subgroup_points(name):
+    """cref.gen_points_unknown_log (random x, square root, cofactor clearing: the reference's bench inputs, helpers/prng_unsafe.nim:306-316,
+    bench_elliptic_parallel_template.nim:78-102) against the big-integer oracle, every curve of the path: on the curve, distinct, [r]P
+    neutral -- and the port's MSM over them equals the oracle's naive sum (Fp square roots by exponentiation / Tonelli-Shanks, Fp2 by the
+    complex method, the G2 cofactors 0x5d54...38e5 and 2p - r: all derived in the port, none shared with the kernels)."""
+    curve = po.CURVES[name]
+    n = 24
+    pts = cref.gen_points_unknown_log(name, 0xABCDEF, n, nthreads=2)
+    again = cref.gen_points_unknown_log(name, 0xABCDEF, 5, first=7, nthreads=1)
+    assert bytes(again) == bytes(pts[7:12])                                   # a slice of the sequence is the sequence
+    P = [curve.aff_from_bytes(bytes(p)) for p in pts]
+    assert len(set(P)) == n and None not in P
+    for p in P:
+        assert curve.is_on_curve(p)
+    for p in P[:4]:
+        assert curve.scalar_mul(curve.order, p) is None
+    sc = cref.synth_scalars(0xABCDF0, n, curve.scalar_bits)
+    ks = [int.from_bytes(bytes(s), "little") for s in sc]
+    want = curve.msm_naive(ks, P)
+    for nt in (1, 3):
+        assert curve.aff_from_bytes(bytes(cref.msm(name, sc, pts, nthreads=nt)[0])) == want
