@@ -23,6 +23,7 @@ bench's definition, one call per iteration, benchmarks/bench_ec_msm_bls12_381_g1
 through the Constantine symbol on host pointers, PCIe included).
 """
 import argparse
+import collections
 import json
 import os
 import socket
@@ -186,6 +187,41 @@ def cpu_model():
     return "unknown CPU"
 
 
+def in_flight_depth(pairs_per_gpu):
+    """MSMs the timed loop keeps in flight: 2, and 3 for small MSMs ($CTT_BENCH_DEPTH overrides; the engine takes at most 3)."""
+    env = os.environ.get("CTT_BENCH_DEPTH")
+    if env:
+        return max(1, min(3, int(env)))
+    return 3 if pairs_per_gpu <= (1 << 17) else 2
+
+
+def measure_hbm_copy_peak(torch, gib=1, reps=6):
+    """'measure with a device copy kernel on the box and use the measured figure alongside the nominal'.  A device-to-device
+    copy of `gib` GiB (16-byte vector loads and stores, torch's copy kernel) reads and writes every byte once: bytes moved = 2 x size.
+    Returns GB/s (best of `reps`, HIP events on torch's current stream), or None when the memory is not there."""
+    try:
+        n = (gib << 30) // 16
+        a = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        b = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        a.fill_(1.0)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None or ms < best else best
+        del a, b
+        torch.cuda.empty_cache()
+        return 2.0 * (gib << 30) / (best * 1e-3) / 1e9
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -325,13 +361,20 @@ def main():
         # One step = one complete MSM.  Two steps are kept in flight: the GPU work of step i+1 is enqueued before the
         # host tail of step i (Horner over windows, affine normalisation, partial-sum exchange) runs, so the GPU never
         # waits for the CPU.  Every step's result is produced inside the timed region.
+        # In flight: two MSMs -- three up to 2^17 pairs per GPU (round 6: the engine has three slots; there the host side of a step, ~0.1 ms of
+        # enqueueing and ~0.15 ms of host tail, is a third of the step, and with two in flight submit(i+2) had to wait for finish(i):
+        # profiles/cu_mask_r06.txt has the timeline and the A/B -- 2^14 -11 %, 2^16 -5 %, 2^17 -3.5 %, level from 2^18 on)
+        depth = in_flight_depth(leg_n)
+
         def run_steps(k, acc=None):
             res = None
-            pending = eng.submit(curve, d_scal, d_points, leg_n) if k > 0 else None
+            queue, submitted = collections.deque(), 0
             in_exchange = None
             for i in range(k):
-                nxt = eng.submit(curve, d_scal, d_points, leg_n) if i + 1 < k else None
-                part = eng.finish(pending, coord="aff")
+                while submitted < k and len(queue) < depth:
+                    queue.append(eng.submit(curve, d_scal, d_points, leg_n))
+                    submitted += 1
+                part = eng.finish(queue.popleft(), coord="aff")
                 if xchg is None:
                     res = part
                 else:
@@ -345,7 +388,6 @@ def main():
                         for key, v in t.items():
                             acc[key] = acc.get(key, 0.0) + v
                         acc["_launches"] = acc.get("_launches", 0) + 1
-                pending = nxt
             if in_exchange is not None:
                 res = xchg.finish(in_exchange)
             return res
@@ -366,7 +408,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         launches = int(acc.pop("_launches", 0))
-        return {"n": leg_n, "first": leg_first, "total": leg_total, "dt": dt, "res": res, "plan": eng.last_plan(),
+        return {"n": leg_n, "first": leg_first, "total": leg_total, "dt": dt, "res": res, "plan": eng.last_plan(), "depth": depth,
                 "stages": {k: v / max(1, launches) for k, v in acc.items()}, "ev_launches": launches,
                 "scal": scal, "d_points": d_points, "d_scal": d_scal}
 
@@ -381,8 +423,9 @@ def main():
                 "scaling": "strong" if leg_strong else "weak", "total_pairs": leg["total"], "pairs_per_gpu_rank0": leg["n"],
                 "window_bits": leg["plan"]["c"], "windows": leg["plan"]["W"], "entries_per_lane": leg["plan"]["K"],
                 "rccl_ranks_seen": ranks_seen(),
-                "workload": f"{curve} MSM, 2^{lg} pairs " + ("in total" if leg_strong else "per GPU") + f", {world} ranks, inputs resident in HBM, two MSMs in flight"}
+                "workload": f"{curve} MSM, 2^{lg} pairs " + ("in total" if leg_strong else "per GPU") + f", {world} ranks, inputs resident in HBM, {leg['depth']} MSMs in flight"}
 
+    hbm_measured = measure_hbm_copy_peak(torch) if rank == 0 else None
     lg = main_total_log2 if strong else args.log2n
     leg = timed_leg(strong, lg)
     n, first, total, dt, res, plan, stages = leg["n"], leg["first"], leg["total"], leg["dt"], leg["res"], leg["plan"], leg["stages"]
@@ -396,10 +439,10 @@ def main():
         "metric": ("MSM points/sec, BLS12-381 G1, 2^20 random pairs" if (curve == "bls12_381_g1" and lg == 20 and (strong or world == 1))
                    else f"MSM points/sec, {curve}, 2^{lg} random pairs")
                   + (f" in total over {world} GPUs" if strong else f" per GPU ({world} x 2^{lg} pairs in one MSM)" if world > 1 else "")
-                  + "; pipelined throughput, 2 MSMs in flight, inputs resident in HBM",
+                  + f"; pipelined throughput, {leg['depth']} MSMs in flight, inputs resident in HBM",
         "value": value,
-        "value_kind": "pipelined: steps / wall time with two complete MSMs in flight (the host tail of MSM i runs under the GPU work of "
-                      "MSM i+1); `value_blocking` = N / latency of ONE blocking call (SURVEY 8d's definition, the reference bench's), "
+        "value_kind": f"pipelined: steps / wall time with {leg['depth']} complete MSMs in flight (the host tail of MSM i runs under the GPU work of "
+                      "the following ones); `value_blocking` = N / latency of ONE blocking call (SURVEY 8d's definition, the reference bench's), "
                       "`value_hostptr` = the same through the Constantine symbol on pageable host arrays (PCIe included)",
         "unit": "points/s",
         "n_gpus": world,
@@ -407,13 +450,13 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if strong else "weak",
+        "scaling": ("strong" if strong else "weak") if world > 1 else "none",
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
         "config": {
             "workload": (f"{curve} MSM, 2^{lg} (scalar,point) pairs " + ("in total" if strong else "per GPU")
-                         + ", inputs resident in HBM, two MSMs in flight" + (f" (BASELINE.json {label})" if label else "")),
+                         + f", inputs resident in HBM, {leg['depth']} MSMs in flight" + (f" (BASELINE.json {label})" if label else "")),
             "pairs_per_gpu": n, "total_pairs": total, "ranks": world, "scalar_bits": info.scalar_bits,
             "window_bits": plan["c"], "windows": plan["W"], "entries_per_lane": plan["K"],
             "sharding": f"points x{world}, asynchronous all_gather of one affine point per rank ({args.backend}), completed one step later, + host sum" if world > 1 else "none",
@@ -459,7 +502,7 @@ def main():
         # ---- the in-library form: ONE process calls the Constantine symbol on host arrays, the library shards the call over the GPUs
         # (ctt_hip_msm_set_devices; what a Constantine caller on an 8-GPU node gets without a source change).  Rank 0 only, the other
         # ranks wait; PCIe included, never `value`.
-        if strong and not args.no_latency and args.all_ranks_on_device < 0:
+        if strong and not args.no_latency:
             if rank == 0:
                 from constantine_amd import multiScalarMul_vartime, multiScalarMul_vartime_parallel
                 from constantine_amd.msm import set_devices
@@ -471,7 +514,9 @@ def main():
                 fn = (lambda s_, p_: multiScalarMul_vartime_parallel(None, curve, s_, p_, coord="jac")) if info.has_parallel \
                     else (lambda s_, p_: multiScalarMul_vartime(curve, s_, p_, coord="jac"))
                 res_h = {}
-                for tag, devs in (("one_device", [local_rank]), ("all_devices", list(range(torch.cuda.device_count())))):
+                # (testing form, --all-ranks-on-device d: "all devices" = d listed once per rank -- the library's sharding over `world` contexts of one GPU)
+                node = list(range(torch.cuda.device_count())) if args.all_ranks_on_device < 0 else [local_rank] * world
+                for tag, devs in (("one_device", [local_rank]), ("all_devices", node)):
                     set_devices(devs if len(devs) > 1 else [])
                     hp = []
                     for _ in range(7):
@@ -482,7 +527,7 @@ def main():
                 set_devices([])
                 torch.cuda.set_device(local_rank)
                 out["hostptr_sharded_ms"] = {"one_device": res_h["one_device"], "all_devices": res_h["all_devices"],
-                                             "devices": torch.cuda.device_count(),
+                                             "devices": len(node), "distinct_devices": len(set(node)),
                                              "note": f"median of 5 calls of the Constantine symbol on pageable host arrays, 2^{lg} pairs, from ONE process "
                                                      "(rank 0; the other ranks idle): the library's own sharding over the node's GPUs, PCIe included"}
             idle_barrier()
@@ -514,7 +559,11 @@ def main():
                 traffic = None
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_accum", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": achieved / HBM_PEAK_GBS,
+            # the same fraction against what a copy kernel reaches on THIS box, measured at the start of this run
+            "peak_measured": hbm_measured, "frac_measured": (achieved / hbm_measured) if hbm_measured else None,
+            "peak_measured_note": "device-to-device copy of 1 GiB (16-byte vectors, read + write counted), best of 6, HIP events; nominal peak beside it",
+            "traffic": traffic, "traffic_source": traffic_src,
             "kernel_ms": stages.get("accumulate", 0.0), "algorithmic_bytes": alg_bytes,
             "note": "integer-VALU bound by construction (no dense contraction); the binding roof is `int_mad` below",
         }

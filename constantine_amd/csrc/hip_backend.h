@@ -27,6 +27,7 @@ __global__ void k_fr_from_mont(const uint32_t* in, uint32_t* out, uint32_t n) {
 
 // --- EC kernels: one lane = one body invocation ----------------------------------------------------
 static constexpr int ACCUM_BLOCK = 64;
+
 static constexpr int EC_BLOCK = 64;
 
 // Input points -> records (msm_bodies.h convert_point_body defines the record).  A lane converts its point into a record
@@ -104,7 +105,7 @@ struct GatherLds {
 };
 template <class F, bool INTO = false>
 __global__ void __launch_bounds__(ACCUM_BLOCK, (sizeof(XYZZ<F>) > 256 ? 1 : CTT_ACCUM_WAVES)) k_accum(AccumArgs<F> a) {
-  if constexpr (F::UNSAT && !IsFp2<F>::value) {
+  if constexpr (F::UNSAT && !IsFp2<F>::value) {   // (not the quadratic extension: msm_bodies.h accum_body_z has the measurement)
     __shared__ uint4 stage[GatherLds<F>::NCH][ACCUM_BLOCK];
     GatherLds<F> gq{stage};
     accum_body<F, GatherLds<F>, INTO>(a, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x, gq);
@@ -501,6 +502,7 @@ struct HipBackend {
     HIP_CHECK(hipStreamWaitEvent(srt, ev_accum_done, 0));
     on_front = true;
   }
+  void front_abort() { on_front = false; accum_marked = false; }
   void front_end() {
     HIP_CHECK(hipEventRecord(ev_front_done, srt));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_front_done, 0));
@@ -627,13 +629,9 @@ struct HipBackend {
     HIP_CHECK(hipSetDevice(device));
     if (uploader_hook) uploader_hook(device);
   }
-  // the helper thread that runs the host tails of pipelined MSMs (MsmEngine::tail_worker): it waits for result copies on this device
-  using GuardScope = ErrorGuard;
-  void tail_worker_begin() {
-    if (hipSetDevice(device) != hipSuccess) (void)hipGetLastError();   // (the first d2h_wait reports it)
-  }
-  [[noreturn]] void tail_worker_failed() {
-    hip_failed("host tail of a pipelined MSM (helper thread)", "the wait for the MSM's result copy failed", 0, __FILE__, __LINE__);
+  using GuardScope = ErrorGuard;   // "this helper thread's HIP failures are thrown, not fatal" (MsmEngine::submit_host's uploader)
+  [[noreturn]] void uploader_failed() {
+    hip_failed("upload of a host-pointer MSM's slices (helper thread)", "a copy or event record failed on the uploader thread", 0, __FILE__, __LINE__);
   }
   void h2d_slice_done(uint32_t i) { HIP_CHECK(hipEventRecord(ev_slice[i], cpy)); }
   void h2d_slice_wait(uint32_t i) { HIP_CHECK(hipStreamWaitEvent(stream, ev_slice[i], 0)); }

@@ -3,7 +3,7 @@
 // The reference's MSM symbols return void and have no error channel (bindings/c_curve_decls_parallel.nim:26-28); its protocol
 // symbols return a status enum and never terminate the process.  This library has no CPU path to fall back to, so:
 //   * every entry point that HAS a return value reports a GPU refusal through it and records WHY in a per-thread "last error"
-//     (ctt_hip_last_error / ctt_hip_last_error_message): -1 refused (bad arguments, both in-flight slots taken), -2 out of device
+//     (ctt_hip_last_error / ctt_hip_last_error_message): -1 refused (bad arguments), -5 busy (all in-flight slots taken), -2 out of device
 //     memory, -3 no usable HIP device, -4 a HIP runtime call failed (the context it happened on is marked lost and refuses
 //     every later call);
 //   * the Constantine-named `void` MSM symbols, which cannot report anything, abort with the same message.
@@ -18,7 +18,8 @@
 
 namespace ctt {
 
-enum { ERR_NONE = 0, ERR_REFUSED = -1, ERR_OUT_OF_MEMORY = -2, ERR_NO_DEVICE = -3, ERR_HIP_FAILURE = -4 };
+// (ERR_BUSY, round 6: "all in-flight slots taken" used to share -1 with bad arguments, and the EVM symbols' retry loop could not tell them apart)
+enum { ERR_NONE = 0, ERR_REFUSED = -1, ERR_OUT_OF_MEMORY = -2, ERR_NO_DEVICE = -3, ERR_HIP_FAILURE = -4, ERR_BUSY = -5 };
 
 struct HipFailure { int code; };
 

@@ -358,9 +358,22 @@ CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq
 }
 
 // the accumulate body in the X, Y + ZZ/ZZZ-holder form (ec.h xyzz_madd_core): used for the quadratic-extension fields.
-// Records are read on demand here: this kernel lives at the edge of its register file (483 of 512 registers, one wave per
-// SIMD), and the pipelined loop order of accum_body_xyzz -- the record collected before the bucket boundary is handled --
-// measured 11 % slower for BLS12-381 G2 on the same box (9.47 -> 10.53 ms at 2^20), with the LDS gather or without.
+// Everything is read ON DEMAND here -- the boundary of the current bucket, the walk over empty buckets, the entry word, then the record:
+// four dependent reads of ~1 us per iteration, 12.4 % of the wave cycles parked on s_waitcnt, 80.6 % VALU-busy with ONE wave per SIMD
+// (483 of 512 registers).  Three ways of hiding those reads were built, and every one measured ~10 % SLOWER on the same box:
+//   round 3   the pipelined loop of accum_body_xyzz (record collected before the boundary block: 57 more registers live across it):
+//             9.47 -> 10.53 ms per MSM at 2^20;
+//   round 6a  the record delivered into LDS by global_load_lds, loop order and register count unchanged (485 registers, 0 scratch,
+//             +1.3 % instructions, the request in front of the 18093 multiply-adds in the ISA): accumulate 8.48 -> 9.17 ms under the
+//             counters, and 17.5 % of the wave cycles parked instead of 12.4 % (profiles/g2_gather_r06.txt; the instruction cache hits
+//             99.9 % in both);
+//   round 6b  no LDS at all: the entry words of pos + 1 / pos + 2 and BucketWalk's look-ahead boundary in three more registers, only the
+//             record read on demand: accumulate 7.99 -> 8.72 ms at 2^20, 2.39 -> 2.65 at 2^18, 0.63 -> 0.71 at 2^16 (same-box A/B against
+//             the round-5 library, two repetitions, profiles/g2_gather_r06.txt).
+// Same arithmetic, same instruction count, fewer exposed reads -- and slower each time.  One guess -- the waves of a CU stop meeting at a
+// wait at the top of every iteration, and the ~220 KB body is fetched through a 64 KB instruction cache that two CUs share -- was tested
+// (round 6c): the four waves of a CU as ONE workgroup with a barrier per iteration.  Slower still (accumulate 7.9 -> 8.9 ms at 2^20, 2.4 -> 5.3
+// at 2^18): it is not that.  The cause is open; EXPERIMENTS.md Part I R6.3 has the counters of every form.  The on-demand loop stays.
 template <class F, class Z, bool INTO = false>
 CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
   if (g >= a.G) return;

@@ -6,10 +6,7 @@
 #include <string.h>
 
 #include <atomic>
-#include <condition_variable>
-#include <deque>
 #include <functional>
-#include <mutex>
 #include <system_error>
 #include <thread>
 #include <type_traits>
@@ -77,8 +74,6 @@ struct MsmOptions {
   // BLS12-381 G1 2^16 0.466-0.473 / 0.480, 2^17 0.654-0.657 / 0.676-0.680, BN254 2^16 0.345 / 0.350 -- the fork's event pair costs what the
   // 25 us of overlap give (gpurun_out/r5i)
   int pyr0_tail = 0;
-  // host tail of an MSM kept in flight (MsmEngine::tail_worker): 0 automatic (a helper thread when the caller pipelines), 1 always, 2 never
-  int async_tail = 0;
 };
 
 // Window size for the GPU pipeline.  The reference's bestBucketBitSize
@@ -408,7 +403,6 @@ struct MsmEngine {
 
   explicit MsmEngine(BK& b) : bk(b) {}
   ~MsmEngine() {
-    tail_worker_stop();
     Buf* all[] = {&part, &gbase, &counts, &entries, &heads, &tails, &hkey, &tkey, &rA[0], &rA[1], &rP[0], &rP[1], &scal, &cpoints, &totals, &mqueue};
     for (int i = 0; i < NSLOT; i++) {
       bk.free_quiet(bstartS[i].p);
@@ -443,9 +437,6 @@ struct MsmEngine {
     bool empty = false;   // len == 0
     void* hraw = nullptr; // pinned host buffer for the device output
     size_t hcap = 0;
-    // host tail on the helper thread (tail_worker): 0 the finishing thread runs it, 1 handed to the helper, 2 result ready, 3 the helper's wait failed
-    std::atomic<int> tail_state{0};
-    XYZZ<HF> tail_result;
   };
   Slot slots[NSLOT];
   int next_slot = 0;
@@ -843,7 +834,6 @@ struct MsmEngine {
     } catch (const OutOfDeviceMemory&) {
       return release_slot(sl);
     }
-    tail_handoff(sl);
     return sl;
   }
   // Only for a caller that is pipelining (the other slot is busy), from ~2^18 pairs on, and while the accumulation is shorter than ~6 ms.
@@ -878,6 +868,7 @@ struct MsmEngine {
   // a submit that ran out of device memory: what it enqueued so far runs to its end on buffers that stay valid (a buffer is
   // only ever freed by need(), and hipFree waits for the device); the slot is free again.  Returns the error value -2.
   int release_slot(int sl) {
+    bk.front_abort();       // (an exception between front_begin and front_end must not leave the next MSM's sort on the front stream: ADVICE r5)
     slots[sl].busy = false;
     next_slot = sl;
     return -2;
@@ -1006,6 +997,7 @@ struct MsmEngine {
     // enqueues slice i's kernels as soon as slice i has been handed to the link.
     bool threaded = BK::THREADED_UPLOAD && nch > 2;   // (two slices: one gap of ~0.1 ms against a thread start of about as much -- measured: 2^18 1.85 ms without, 1.93 with)
     std::atomic<uint32_t> uploaded{0}, coefs_up{0};
+    std::atomic<bool> upload_failed{false};   // a HIP call failed on the uploader thread: reported by THIS thread (the one an entry point's error channel belongs to)
     std::thread uploader;
     struct Joiner {
       std::thread& t;
@@ -1014,6 +1006,10 @@ struct MsmEngine {
     if (threaded) {
       try {
         uploader = std::thread([&]() {
+          // (a failed copy on this thread must not abort a process whose entry point can report: the guard makes HIP_CHECK throw here,
+          // the flag hands the failure to the submitting thread -- ADVICE r5; the emulator's guard is empty)
+          typename BK::GuardScope guard;
+          try {
           bk.uploader_begin();
           for (uint32_t i = 0; i < nch; i++) {
             upload_coefs(i);
@@ -1028,6 +1024,11 @@ struct MsmEngine {
             bk.h2d_slice_done(i);
             uploaded.store(i + 1, std::memory_order_release);
           }
+          } catch (...) {
+            upload_failed.store(true, std::memory_order_release);
+            coefs_up.store(nch, std::memory_order_release);     // (release the submitting thread's waits)
+            uploaded.store(nch, std::memory_order_release);
+          }
         });
       } catch (const std::system_error&) {
         threaded = false;   // (no thread to be had: this one copies, as with two slices)
@@ -1038,10 +1039,11 @@ struct MsmEngine {
       bk.stage_chunk((int)i);   // stage events of this slice (the stage times of the call are the sums over its slices)
       uint32_t* d_c = (uint32_t*)d_stage_coefs + (size_t)start * 8;
       Affine<F>* d_p = (Affine<F>*)d_stage_points + start;
-      auto await = [](std::atomic<uint32_t>& flag, uint32_t i) {
+      auto await = [&](std::atomic<uint32_t>& flag, uint32_t i) {
         for (uint32_t spin = 0; flag.load(std::memory_order_acquire) <= i; spin++) {
           if (spin < 20000u) cpu_relax(); else std::this_thread::yield();
         }
+        if (upload_failed.load(std::memory_order_acquire)) bk.uploader_failed();   // (throws to the entry point's boundary, or aborts where there is none)
       };
       // The first slice starts on its coefficients: the digits and the sort need nothing else, and they run while the slice's points
       // cross the link (accumulate_pairs, points_arrive).  Later slices wait for both copies at once (their sort queues behind the
@@ -1101,14 +1103,24 @@ struct MsmEngine {
     } catch (const OutOfDeviceMemory&) {
       return release_slot(sl);
     }
-    tail_handoff(sl);
     return sl;
   }
   uint32_t last_chunks = 1;
 
   // Host tail of a submitted MSM: wait for its W window sums, Horner over the windows.
-  XYZZ<HF> host_tail(int sl) {
+  // (Round 6 built this tail on a helper thread of the engine -- handed over at the end of submit(), finish() only collecting the result --
+  // on the reading that the caller's thread, 0.1 ms of enqueueing + 0.1-0.2 ms of tail per MSM, is what starves the main stream of a small
+  // pipelined MSM.  Measured, same box, same process, finishing thread / helper thread: 2^14 0.310 / 0.309 ms per MSM, 2^16 0.428 / 0.428,
+  // 2^17 0.601 / 0.604 with three in flight, 2^16 0.449 / 0.444 with two -- nothing: with a third slot the GPU has the next MSM queued
+  // whatever the host does meanwhile.  Removed again; EXPERIMENTS.md has the table.)
+  XYZZ<HF> finish(int sl) {
     Slot& S = slots[sl];
+    if (!S.busy) {
+      fprintf(stderr, "[ctt_msm] FATAL: finish() of a slot that was not submitted\n");
+      abort();
+    }
+    S.busy = false;
+    if (S.empty) return XYZZ<HF>::inf();
     bk.d2h_wait(sl);
     const MsmPlan& p = S.plan;
     const XYZZ<FD>* raw = (const XYZZ<FD>*)S.hraw;
@@ -1116,93 +1128,6 @@ struct MsmEngine {
     std::vector<XYZZ<HF>> sums(cnt);
     for (size_t i = 0; i < cnt; i++) sums[i] = xyzz_to_host<FD>(raw[i]);
     return combine_groups<HF>(sums.data(), p.W, p.lay, p.h, p.ngrp);
-  }
-  // The host tail on a thread of its own (round 6).  A caller that keeps small MSMs in flight spends, per MSM, ~0.1 ms enqueueing the
-  // launches and 0.1-0.2 ms in the host tail (W c doublings, one core) -- 0.3 of a 0.45 ms step at 2^16 pairs, on ONE thread, with the
-  // next submit behind the previous finish.  The timeline (profiles/cu_mask_r06.txt) shows the main stream idle ~90 us per step waiting
-  // for launches that have not been enqueued yet.  With the tail handed to a helper at the end of submit(), the caller's finish() only
-  // collects the result, and its thread is free to enqueue.  Only for a caller that pipelines (another slot busy at submit time): a lone
-  // blocking call would pay two thread hand-offs for nothing.
-  std::thread tail_thread;
-  std::mutex tail_mu;
-  std::condition_variable tail_cv;
-  std::deque<int> tail_queue;
-  bool tail_stop = false;
-  void tail_worker() {
-    bk.tail_worker_begin();
-    for (;;) {
-      int sl;
-      {
-        std::unique_lock<std::mutex> lk(tail_mu);
-        tail_cv.wait(lk, [&]() { return tail_stop || !tail_queue.empty(); });
-        if (tail_queue.empty()) return;   // (stop)
-        sl = tail_queue.front();
-        tail_queue.pop_front();
-      }
-      Slot& S = slots[sl];
-      int done = 2;
-      try {
-        // (a failed HIP call on this thread must reach the caller of finish(), not abort the process: BK::guard_scope is the backend's
-        // "this thread can report" marker -- hip_errors.h ErrorGuard for the GPU, nothing for the emulator)
-        typename BK::GuardScope guard;
-        S.tail_result = host_tail(sl);
-      } catch (...) {
-        done = 3;
-      }
-      S.tail_state.store(done, std::memory_order_release);
-    }
-  }
-  void tail_worker_stop() {
-    if (!tail_thread.joinable()) return;
-    {
-      std::lock_guard<std::mutex> lk(tail_mu);
-      tail_stop = true;
-    }
-    tail_cv.notify_all();
-    tail_thread.join();
-  }
-  void tail_handoff(int sl) {
-    Slot& S = slots[sl];
-    S.tail_state.store(0, std::memory_order_relaxed);
-    if (S.empty || opt.async_tail == 2) return;
-    if (opt.async_tail != 1 && !other_busy(sl)) return;
-    if (!tail_thread.joinable()) {
-      try {
-        tail_thread = std::thread([this]() { tail_worker(); });
-      } catch (const std::system_error&) {
-        return;                           // (no thread to be had: the finishing thread runs the tail, as before)
-      }
-    }
-    S.tail_state.store(1, std::memory_order_relaxed);
-    {
-      std::lock_guard<std::mutex> lk(tail_mu);
-      tail_queue.push_back(sl);
-    }
-    tail_cv.notify_one();
-  }
-  XYZZ<HF> finish(int sl) {
-    Slot& S = slots[sl];
-    if (!S.busy) {
-      fprintf(stderr, "[ctt_msm] FATAL: finish() of a slot that was not submitted\n");
-      abort();
-    }
-    if (S.empty) {
-      S.busy = false;
-      return XYZZ<HF>::inf();
-    }
-    if (S.tail_state.load(std::memory_order_acquire) == 0) {
-      const XYZZ<HF> r = host_tail(sl);    // (may throw through HIP_CHECK: the slot then stays claimed on a context that is lost anyway)
-      S.busy = false;
-      return r;
-    }
-    int st;
-    for (uint32_t spin = 0; (st = S.tail_state.load(std::memory_order_acquire)) == 1; spin++) {
-      if (spin < 4000u) cpu_relax(); else std::this_thread::yield();
-    }
-    S.tail_state.store(0, std::memory_order_relaxed);
-    S.busy = false;
-    if (st == 3) bk.tail_worker_failed();  // (throws or aborts like the HIP_CHECK that failed on the helper thread)
-    return S.tail_result;
   }
 
   bool in_flight(int sl) const { return sl >= 0 && sl < NSLOT && slots[sl].busy; }

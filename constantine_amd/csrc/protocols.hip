@@ -822,11 +822,11 @@ static int evm_validate_and_msm(int curve, void* r_aff, const void* coefs, const
     for (size_t i = 0; i < n; i++)
       if (!ok[i]) return EVM_PointNotInSubgroup;
   }
-  // The MSM.  A refusal because both in-flight slots of the context are held by another thread's device-resident tickets passes:
-  // wait for it (up to ~2 s) instead of failing a consensus call; anything else (no device, out of device memory, a HIP failure)
-  // comes back as GPU_UNAVAILABLE with the thread's last error set -- rounds 1-4 aborted the process here.
+  // The MSM.  A refusal because all in-flight slots of the context are held by another thread's device-resident tickets (ERR_BUSY)
+  // passes: wait for it (up to ~2 s) instead of failing a consensus call; anything else (bad arguments, no device, out of device
+  // memory, a HIP failure) comes back as GPU_UNAVAILABLE at once with the thread's last error set -- rounds 1-4 aborted the process here.
   int rc = ctt_hip_msm_host(curve, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, coefs, pts, n);
-  for (int spin = 0; rc == -1 && ctt_hip_last_error() == ERR_REFUSED && spin < 20000; spin++) {
+  for (int spin = 0; rc == -1 && ctt_hip_last_error() == ERR_BUSY && spin < 20000; spin++) {
     std::this_thread::sleep_for(std::chrono::microseconds(100));
     rc = ctt_hip_msm_host(curve, CTT_HIP_COEF_BIG, CTT_HIP_OUT_AFF, r_aff, coefs, pts, n);
   }

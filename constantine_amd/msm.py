@@ -112,7 +112,7 @@ class DeviceMsm:
             self.ctx = None
 
     def set_option(self, key, value):
-        """ctt_hip_msm_set_option: "c", "K", "S", "chunks", "horner_bits", "host_window_sums", "sort_staged", "sort_xcd", "timings", "timings_every", "async_tail"
+        """ctt_hip_msm_set_option: "c", "K", "S", "chunks", "horner_bits", "host_window_sums", "sort_staged", "sort_xcd", "timings", "timings_every"
         (include/ctt_msm_hip.h); 0 = automatic / off.  KeyError for an unknown key."""
         if self.L.ctt_hip_msm_set_option(self.ctx, key.encode(), int(value)) != 0:
             raise KeyError(key)

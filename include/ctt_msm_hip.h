@@ -143,8 +143,9 @@ CTT_BATCH_AFFINE_DECL(vesta_ec_prj, vesta_ec_aff)
  * a binding makes once), else 0.
  *
  * Why a call was refused -- per thread, set by every symbol of this header that returns an error value (NULL, -1, -2, or Part 3's
- * CTT_HIP_STATUS_GPU_UNAVAILABLE); a successful call leaves it alone:
- *    0 none   -1 refused (bad arguments; all in-flight slots of the context taken)   -2 out of device memory
+ * CTT_HIP_STATUS_GPU_UNAVAILABLE), and cleared when such a symbol is entered (round 6: no stale code of an earlier call):
+ *    0 none   -1 refused (bad arguments: curve id, kind, length, ticket, option key, owner)   -2 out of device memory
+ *   -5 busy: all in-flight slots of the context are taken -- finish a ticket, or retry (round 6; was -1)
  *   -3 no usable HIP device   -4 a HIP runtime call failed: the context it happened on is LOST -- every later call on it is
  *      refused with -4; destroy it and create a new one (the default context of the host-pointer symbols stays lost) */
 int ctt_hip_last_error(void);
@@ -182,9 +183,7 @@ void ctt_hip_msm_ctx_destroy(ctt_hip_msm_ctx* ctx);
  * "horner_bits" bits per group of the bit Horner the device runs per window (0 = 4; the host joins the groups),
  * "host_window_sums" (legacy spelling: 1 = groups of one bit, 2 = one group per window), "timings" 1 = record the
  * stage events ctt_hip_msm_last_timings reads (2 = the accumulate stage and the total only), "timings_every" k = only every
- * k-th MSM records them (the others report zeros; default 1), "async_tail" the host tail of an MSM submitted while another is
- * outstanding runs on a helper thread of the context (0 automatic = yes, 1 also for lone calls, 2 never: the finishing thread runs it).
- * value 0 = automatic / off.  Returns 0, or -1 for an unknown key.
+ * k-th MSM records them (the others report zeros; default 1).  value 0 = automatic / off.  Returns 0, or -1 for an unknown key.
  * A context created with $CTT_HIP_CU_TAIL = r > 0 partitions the chip: its tail stream runs on r compute units of every XCD
  * (hipExtStreamCreateWithCUMask), its main stream on the others -- an experiment of round 6, measured slower than sharing the chip
  * (profiles/cu_mask_r06.txt); such streams are BLOCKING streams: do not order them behind the legacy null stream. */

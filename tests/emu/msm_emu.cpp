@@ -38,6 +38,7 @@ struct EmuBackend {
   void wide_wait() {}
   void front_begin() {}
   void front_end() {}
+  void front_abort() {}
   void accum_mark(bool) {}
   void stage_chunk(int) {}
   void d2h_sync(void* dst, const void* src, size_t b) { memcpy(dst, src, b); }
@@ -46,8 +47,7 @@ struct EmuBackend {
   static constexpr bool THREADED_UPLOAD = true;   // (the slices of submit_host are copied by a thread here too: same code path)
   void uploader_begin() {}
   struct GuardScope {};
-  void tail_worker_begin() {}
-  [[noreturn]] void tail_worker_failed() { abort(); }
+  [[noreturn]] void uploader_failed() { abort(); }
   void h2d_slice_done(uint32_t) {}
   void h2d_slice_wait(uint32_t) {}
   void h2d_coefs_done(uint32_t) {}

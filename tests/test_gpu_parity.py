@@ -1042,6 +1042,59 @@ def test_zal_cached_base_descriptor_from_c(tmp_path):
     assert int.from_bytes(out[-4:], "little", signed=True) > 0                                # the descriptor is a window table
 
 
+def test_concurrent_callers_overlap_on_their_own_contexts():
+    """Round 6 (review item 8): the reference's `_parallel` MSM may be called from several threads at once, each with its own pool
+    (include/constantine/core/threadpool.h:25-39; "can be nested", ec_multi_scalar_mul_parallel.nim:596).  Here every calling thread gets a
+    context of its own (up to $CTT_HIP_HOST_CONTEXTS, default 4) instead of taking turns on one: a blocking 2^16-pair call keeps the chip
+    busy for about a third of its 0.9 ms, so the chains of several callers overlap.  2 and 4 threads x 2^16 pairs through the Constantine
+    symbol: every result against the oracle, and the aggregate rate against one thread's (measured on the builder's box: 1.62 x with two
+    threads, 2.11 x with four -- profiles/concurrent_callers_r06.txt; the bars here leave room for a noisy box)."""
+    import threading
+    import time
+    from constantine_amd import multiScalarMul_vartime_parallel
+    name = "bls12_381_g1"
+    curve = po.CURVES[name]
+    n = 1 << 16
+    pts = cref.gen_points(name, 2100, n)
+    inputs, expect = [], []
+    for t in range(4):
+        sc = cref.synth_scalars(2200 + t, n, 255)
+        inputs.append(sc)
+        expect.append(_aff(curve, cref.msm(name, sc, pts, nthreads=NT)[0]))
+    calls = 30
+    old = os.environ.get("CTT_HIP_HOST_CONTEXTS")
+    os.environ["CTT_HIP_HOST_CONTEXTS"] = "4"
+
+    def run(T):
+        got = [None] * T
+
+        def work(t):
+            for _ in range(calls):
+                got[t] = multiScalarMul_vartime_parallel(None, name, inputs[t], pts, coord="jac")
+        rate = 0.0
+        for _ in range(2):          # (the first repetition opens the contexts and grows their workspaces)
+            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            rate = T * calls / (time.perf_counter() - t0)
+        for t in range(T):
+            assert _decode(curve, "jac", got[t]) == expect[t], (T, t)
+        return rate
+    try:
+        r1, r2, r4 = run(1), run(2), run(4)
+    finally:
+        if old is None:
+            os.environ.pop("CTT_HIP_HOST_CONTEXTS", None)
+        else:
+            os.environ["CTT_HIP_HOST_CONTEXTS"] = old
+    print(f"concurrent callers, 2^16 pairs per call: {r1:.0f} / {r2:.0f} / {r4:.0f} calls/s with 1 / 2 / 4 threads ({r2 / r1:.2f} x, {r4 / r1:.2f} x)")
+    assert r2 >= 1.3 * r1, (r1, r2)
+    assert r4 >= 1.5 * r1, (r1, r4)
+
+
 def test_concurrent_callers_are_serialised():
     """Several host threads calling the Constantine symbols at once (the reference allows MSM calls from inside
     pool tasks, ec_multi_scalar_mul_parallel.nim:596; KZG batch verification issues three at a time): the engine

@@ -72,10 +72,12 @@ for cfg in "bn254_snarks_g1 22" "pallas 20" "bls12_381_g2 20" "bls12_381_g1 16" 
 done
 
 # the other BASELINE configs and the size sweep
-timeout 300 python bench.py --curve bn254_snarks_g1 --log2n 22 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bn254_snarks_g1.json" 2>> "$OUT/bench.err"
-timeout 300 python bench.py --curve pallas --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_pallas.json" 2>> "$OUT/bench.err"
-timeout 300 python bench.py --curve vesta --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_vesta.json" 2>> "$OUT/bench.err"
-timeout 300 python bench.py --curve bls12_381_g2 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g2.json" 2>> "$OUT/bench.err"
+# (the lines of the other BASELINE configs keep their CPU / parity leg: `parity_vs_oracle_on_sample` and `parity_full_size_vs_discrete_logs`
+# are true / false in every configs[] line, not null -- round-5 review)
+timeout 400 python bench.py --curve bn254_snarks_g1 --log2n 22 --steps 20 --warmup 3 > "$OUT/bench_${TAG}_bn254_snarks_g1.json" 2>> "$OUT/bench.err"
+timeout 400 python bench.py --curve pallas --steps 20 --warmup 3 > "$OUT/bench_${TAG}_pallas.json" 2>> "$OUT/bench.err"
+timeout 400 python bench.py --curve vesta --steps 20 --warmup 3 > "$OUT/bench_${TAG}_vesta.json" 2>> "$OUT/bench.err"
+timeout 400 python bench.py --curve bls12_381_g2 --steps 20 --warmup 3 > "$OUT/bench_${TAG}_bls12_381_g2.json" 2>> "$OUT/bench.err"
 for k in 16 17 18 19 22 24; do
   timeout 300 python bench.py --log2n $k --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${TAG}_bls12_381_g1_2pow$k.json" 2>> "$OUT/bench.err"
 done
@@ -92,6 +94,7 @@ timeout 300 python tools/sweep.py bls12_381_g1 6 c=0 -- bls12_381_g1 8 c=0 -- bl
     -- bls12_381_g1 20 c=0 -- bls12_381_g1 22 c=0 -- bls12_381_g1 24 c=0 -- bls12_381_g2 18 c=0 -- bls12_381_g2 20 c=0 -- bn254_snarks_g1 16 c=0 -- bn254_snarks_g1 20 c=0,16,17 -- bn254_snarks_g1 22 c=0 \
     -- pallas 20 c=0 -- vesta 20 c=0 -- bn254_snarks_g2 18 c=0 > "$OUT/sweep_sizes_$TAG.jsonl" 2>> "$OUT/bench.err"
 timeout 300 python tools/bench_hostptr.py > "$OUT/hostptr_$TAG.txt" 2>> "$OUT/bench.err"
+timeout 300 python tools/bench_threads.py 16 40 > "$OUT/concurrent_callers_collection_$TAG.txt" 2>> "$OUT/bench.err"
 # cached bases with a window table next to the plain records (same box, same inputs): ms per pipelined step + stage times
 {
   timeout 300 python tools/bench_table.py bls12_381_g1 20 0 19 21
@@ -104,6 +107,8 @@ timeout 300 python tools/bench_hostptr.py > "$OUT/hostptr_$TAG.txt" 2>> "$OUT/be
 } 2>> "$OUT/bench.err" | grep '^{' > "$OUT/table_$TAG.jsonl"
 # the N-GPU line's code path end to end on this one GPU: two ranks sharing device 0 with a gloo exchange (a plumbing check, not a scaling point)
 timeout 300 python bench.py --gpus 2 --all-ranks-on-device 0 --backend gloo --steps 10 --warmup 2 > "$OUT/bench_${TAG}_2ranks_one_gpu_gloo.json" 2>> "$OUT/bench.err"
+# ... and the driver's 8-rank form with every leg of the line (strong 2^20, weak, configs[3] 2^24 in total, strong_bound, hostptr_sharded_ms over 8 contexts): plumbing only
+timeout 600 python bench.py --gpus 8 --all-ranks-on-device 0 --backend gloo --steps 3 --warmup 1 > "$OUT/bench_${TAG}_8ranks_one_gpu_gloo.json" 2>> "$OUT/bench.err"
 # same box, the previous round's library next to this one (tools/libctt_msm_hip_prev.so, built from the previous round's commit)
 if [ -f tools/libctt_msm_hip_prev.so ]; then
   { for a in "--log2n 16" "--log2n 17" "--log2n 18" "--log2n 19" "" "--curve bn254_snarks_g1 --log2n 20" "--curve bn254_snarks_g1 --log2n 22" "--curve pallas" "--curve bls12_381_g2 --log2n 18"; do

@@ -175,6 +175,47 @@ int main(int argc, char** argv) {
     CK(hipStreamDestroy(a));
     CK(hipStreamDestroy(b));
   }
+  // ---- (3) two chains of dependent short launches on two streams at once (the main-stream chain of a small MSM beside the previous
+  // MSM's tail chain): does a second active hardware queue delay dependent launches?  k dummy streams are created between the two
+  // (hardware queues are handed out in creation order; queues that share a pipe of the command processor take turns)
+  for (int dummies : {0, 1, 2, 3, 5}) {
+    hipStream_t a, b, d[8];
+    CK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    for (int i = 0; i < dummies; i++) {
+      CK(hipStreamCreateWithFlags(&d[i], hipStreamNonBlocking));
+      hipLaunchKernelGGL(k_short, dim3(1), dim3(64), 0, d[i], d_out + (4u << 20), 1);   // (a stream gets its queue with its first work)
+    }
+    CK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+    CK(hipDeviceSynchronize());
+    hipEvent_t a0, a1, b0, b1;
+    CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1)); CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+    const int len = 40;
+    float ta = 0, tb = 0, alone = 0;
+    for (int rep = 0; rep < 3; rep++) {
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(a0, a));
+      for (int i = 0; i < len; i++) hipLaunchKernelGGL(k_short, dim3(64), dim3(64), 0, a, d_out, 400);
+      CK(hipEventRecord(a1, a));
+      CK(hipDeviceSynchronize());
+      CK(hipEventElapsedTime(&alone, a0, a1));
+      CK(hipEventRecord(a0, a));
+      CK(hipEventRecord(b0, b));
+      for (int i = 0; i < len; i++) {
+        hipLaunchKernelGGL(k_short, dim3(64), dim3(64), 0, a, d_out, 400);
+        hipLaunchKernelGGL(k_short, dim3(64), dim3(64), 0, b, d_out + (2u << 20), 400);
+      }
+      CK(hipEventRecord(a1, a));
+      CK(hipEventRecord(b1, b));
+      CK(hipDeviceSynchronize());
+      CK(hipEventElapsedTime(&ta, a0, a1));
+      CK(hipEventElapsedTime(&tb, b0, b1));
+    }
+    printf("two chains of %d dependent 64-wave launches, %d dummy streams between: alone %.1f us per launch; together %.1f / %.1f us per launch\n", len, dummies,
+           alone * 1e3 / len, ta * 1e3 / len, tb * 1e3 / len);
+    CK(hipStreamDestroy(a));
+    CK(hipStreamDestroy(b));
+    for (int i = 0; i < dummies; i++) CK(hipStreamDestroy(d[i]));
+  }
   // the busy kernel alone, masked and unmasked (what the reserved CUs cost it): same work per wave, fewer waves
   {
     hipStream_t a;
