@@ -36,7 +36,7 @@ import numpy as np
 
 # A process gets four hardware queues by default; the engine's context uses three streams (main, tail, copy) beside the null stream, and
 # torch / RCCL bring their own.  Streams beyond the fourth share a hardware queue with another one -- measured: a fifth stream cost every
-# small pipelined MSM 8 % without a kernel on it.  Must be set before the HIP runtime initialises; neutral for one rank.
+# small pipelined MSM 8 % without a kernel on it (EXPERIMENTS.md II section 5).  Must be set before the HIP runtime initialises; neutral for one rank.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -44,7 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-# v_mad_u64_u32 per mixed addition of the accumulate kernel, as executed (ISA count of the hot path):
+# v_mad_u64_u32 per mixed addition of the accumulate kernel, as executed (ISA count of the hot path, DESIGN.md 3.3 / EXPERIMENTS.md II 4.3):
 # 8 products + 2 squares + 9 Montgomery reductions on NL carry-free limbs = 8 NL^2 + NL (NL + 1) + 9 NL^2 (NL = 14 for
 # BLS12-381, 9 for BN254); the Pasta primes have three zero limbs and p_0 = 1, which drop products: 1224.
 # G2: the same formula over Fp2 -- a product is 4 base products + 2 reductions, a square 2 + 2.
@@ -188,11 +188,14 @@ def cpu_model():
 
 
 def in_flight_depth(pairs_per_gpu):
-    """MSMs the timed loop keeps in flight: 2, and 3 for small MSMs ($CTT_BENCH_DEPTH overrides; the engine takes at most 3)."""
+    """MSMs the timed loop keeps in flight: 2, and 3 for small MSMs ($CTT_BENCH_DEPTH overrides; the engine takes at most 3).
+    Three pay up to 2^16 pairs on every box measured (2^14 -8 ... -11 %, 2^16 -4.5 ... -5.7 %).  At 2^17-2^18 the third MSM is a race: the previous
+    MSM's tail runs beside an accumulation that now always follows at once, and when it loses, the first reduction pass waits for it -- 2^17
+    0.62 -> 0.60 ms per MSM on two boxes, 0.63 -> 0.72 and 0.68 -> 0.81 on two others (profiles/cu_mask_r06.txt section 4).  Two there."""
     env = os.environ.get("CTT_BENCH_DEPTH")
     if env:
         return max(1, min(3, int(env)))
-    return 3 if pairs_per_gpu <= (1 << 17) else 2
+    return 3 if pairs_per_gpu <= (1 << 16) else 2
 
 
 def measure_hbm_copy_peak(torch, gib=1, reps=6):
@@ -361,9 +364,9 @@ def main():
         # One step = one complete MSM.  Two steps are kept in flight: the GPU work of step i+1 is enqueued before the
         # host tail of step i (Horner over windows, affine normalisation, partial-sum exchange) runs, so the GPU never
         # waits for the CPU.  Every step's result is produced inside the timed region.
-        # In flight: two MSMs -- three up to 2^17 pairs per GPU (round 6: the engine has three slots; there the host side of a step, ~0.1 ms of
+        # In flight: two MSMs -- three up to 2^16 pairs per GPU (round 6: the engine has three slots; there the host side of a step, ~0.1 ms of
         # enqueueing and ~0.15 ms of host tail, is a third of the step, and with two in flight submit(i+2) had to wait for finish(i):
-        # profiles/cu_mask_r06.txt has the timeline and the A/B -- 2^14 -11 %, 2^16 -5 %, 2^17 -3.5 %, level from 2^18 on)
+        # profiles/cu_mask_r06.txt has the timeline and the A/B; in_flight_depth has why not above 2^16)
         depth = in_flight_depth(leg_n)
 
         def run_steps(k, acc=None):
@@ -489,7 +492,7 @@ def main():
                 "ms_per_step_one_gpu_same_run": solo_ms,
                 "speedup_vs_one_gpu_same_run": (solo_ms / (dt / args.steps * 1e3)) if solo_ms else None,
                 "speedup_bound_from_shard_time": (solo_ms / own_ms) if solo_ms else None,
-                "note": "2^%d / %d pairs per rank: a small MSM is a chain of dependent launches (DESIGN.md section 6: 2.9 / 1.7 / 1.0 / 0.65 ms for "
+                "note": "2^%d / %d pairs per rank: a small MSM is a chain of dependent launches (DESIGN.md section 5: 2.8 / 1.7 / 1.1 / 0.70 ms for "
                         "2^20 / 2^19 / 2^18 / 2^17 pairs on one GPU), so the split of a FIXED 2^20-pair job is bounded well below N x" % (lg, world)}
         # ---- the other forms of the same job, same run (driver form only: `--gpus N` with no size flag) --------------------------
         if driver_form:
@@ -575,7 +578,7 @@ def main():
                 "frac_vs_round1_peak_31T": mads / t_acc / INT_MAD_PEAK_R01,
                 "note": "the multiply-adds are ~78 % of the kernel's VALU instructions; every VOP3 instruction issues at the same "
                         "~4.5 cycles per wave (profiles/microbench_isa_r02.jsonl), so the kernel's own roof is its instruction "
-                        "count: profiles/pmc_r05_sq_counters_k_accum_*.txt: 4558 VALU instructions per mixed addition for 3542 multiply-adds (DESIGN.md 4.3 has the account per class)",
+                        "count: profiles/pmc_r06_sq_counters_k_accum_*.txt: 4558 VALU instructions per mixed addition for 3542 multiply-adds (DESIGN.md 3.3; EXPERIMENTS.md II 4.3 has the account per class)",
             }
 
     # ---- the reference bench's own definition: one blocking call per iteration ----------------------------

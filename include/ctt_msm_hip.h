@@ -197,7 +197,8 @@ int ctt_hip_msm_device(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, int out_k
  * when three tickets are outstanding on the curve (two in rounds 1-5); finish waits for the ticket, runs the host tail (Horner over
  * windows, affine normalisation) and writes r (0, or -1 for a ticket that is not outstanding).  Submitting MSM i+1 before
  * finishing MSM i overlaps the host tail of i with the GPU work of i+1 (how bench.py keeps the GPU busy); a caller of SMALL MSMs
- * (up to ~2^18 pairs: the host tail and the enqueueing are a third of a step there) keeps three outstanding -- submit i+2, then finish i. */
+ * (up to ~2^16 pairs: the host tail and the enqueueing are a third of a step there; above, the third MSM only crowds the second one's tail)
+ * keeps three outstanding -- submit i+2, then finish i. */
 int ctt_hip_msm_device_submit(ctt_hip_msm_ctx* ctx, int curve, int coef_kind, const void* d_coefs, const void* d_points,
                               size_t len);
 int ctt_hip_msm_device_finish(ctt_hip_msm_ctx* ctx, int ticket, int out_kind, void* r);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rate of the Constantine-compatible symbol (host pointers, pageable memory), DESIGN.md section 6.
+"""PCIe-inclusive rate of the Constantine-compatible symbol (host pointers, pageable memory), DESIGN.md section 4.
 Also times the KZG commitment path (cached SRS, host scalars).  Never the headline `value` (inputs there are in HBM)."""
 import os
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print the round's measurement table (DESIGN.md section 6) from profiles/bench_<tag>*.json: python tools/design_table.py r03"""
+"""Print the round's measurement table (DESIGN.md section 5) from profiles/bench_<tag>*.json: python tools/design_table.py r03"""
 import json
 import os
 import sys

@@ -1,0 +1,18 @@
+import os, sys, time
+sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd())
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+from constantine_amd import CURVES, DeviceMsm, multiScalarMul_vartime_parallel
+from constantine_amd.synth import synth_scalars
+from constantine_amd import _lib
+name = "bls12_381_g1"; info = CURVES[name]
+for n in (1 << 18, 3 << 17, 1 << 19, 3 << 18, 1 << 20):
+    eng = DeviceMsm(0)
+    d = torch.empty((n, info.aff_bytes), dtype=torch.uint8, device="cuda")
+    eng.gen_points(name, 5, n, d); pts = d.cpu().numpy(); eng.close()
+    sc = synth_scalars(6, n, 255)
+    ts = []
+    for i in range(9):
+        t0 = time.perf_counter(); multiScalarMul_vartime_parallel(None, name, sc, pts, coord="jac"); ts.append((time.perf_counter() - t0) * 1e3)
+    plan = (8 * 4) 
+    print(os.path.basename(os.environ.get("CTT_MSM_HIP_LIB", "in-tree")), "n =", n, "ms:", " ".join(f"{t:.2f}" for t in ts), flush=True)
