@@ -61,7 +61,16 @@ static hipStream_t masked_stream(const std::vector<uint32_t>& mask) {
   return s;
 }
 
+// a tiny kernel of wide workgroups (the sort's scan kernels: 20 x 1024 lanes, a few microseconds)
+__global__ void __launch_bounds__(1024) k_tiny_wide(uint32_t* out, int iters) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t a = tid;
+  for (int it = 0; it < iters; it++) a = a * 1664525u + 1013904223u;
+  out[tid] = a;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1) setenv("GPU_MAX_HW_QUEUES", argv[1], 1);   // (before the first HIP call; default: the runtime's four)
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   const int ncu = prop.multiProcessorCount;
@@ -212,6 +221,47 @@ int main(int argc, char** argv) {
     }
     printf("two chains of %d dependent 64-wave launches, %d dummy streams between: alone %.1f us per launch; together %.1f / %.1f us per launch\n", len, dummies,
            alone * 1e3 / len, ta * 1e3 / len, tb * 1e3 / len);
+    CK(hipStreamDestroy(a));
+    CK(hipStreamDestroy(b));
+    for (int i = 0; i < dummies; i++) CK(hipStreamDestroy(d[i]));
+  }
+  // ---- (4) the shape seen in the MSM timelines: the main stream's chain of SHORT kernels with wide workgroups (count / scan / scatter of the
+  // sort) beside the tail stream's chain of ~9 us kernels with many one-wave workgroups (narrow reduction passes), the latter on a
+  // high-priority stream; k dummy streams between the two
+  for (int dummies : {0, 1, 2, 3, 4, 5, 6}) {
+    hipStream_t a, b, d[8];
+    CK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    for (int i = 0; i < dummies; i++) {
+      CK(hipStreamCreateWithFlags(&d[i], hipStreamNonBlocking));
+      hipLaunchKernelGGL(k_short, dim3(1), dim3(64), 0, d[i], d_out + (4u << 20), 1);
+    }
+    int lo = 0, hi = 0;
+    CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CK(hipStreamCreateWithPriority(&b, hipStreamNonBlocking, hi));
+    CK(hipDeviceSynchronize());
+    hipEvent_t a0, a1, b0, b1;
+    CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1)); CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+    const int len = 40;
+    float ta = 0, tb = 0, alone = 0;
+    for (int rep = 0; rep < 3; rep++) {
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(a0, a));
+      for (int i = 0; i < len; i++) hipLaunchKernelGGL(k_tiny_wide, dim3(20), dim3(1024), 0, a, d_out, 200);
+      CK(hipEventRecord(a1, a));
+      CK(hipDeviceSynchronize());
+      CK(hipEventElapsedTime(&alone, a0, a1));
+      CK(hipEventRecord(b0, b));
+      for (int i = 0; i < len; i++) hipLaunchKernelGGL(k_short, dim3(1280), dim3(64), 0, b, d_out + (2u << 20), 500);
+      CK(hipEventRecord(b1, b));
+      CK(hipEventRecord(a0, a));
+      for (int i = 0; i < len; i++) hipLaunchKernelGGL(k_tiny_wide, dim3(20), dim3(1024), 0, a, d_out, 200);
+      CK(hipEventRecord(a1, a));
+      CK(hipDeviceSynchronize());
+      CK(hipEventElapsedTime(&ta, a0, a1));
+      CK(hipEventElapsedTime(&tb, b0, b1));
+    }
+    printf("short wide-workgroup chain beside a high-priority chain of 1280-wave launches, %d dummy streams between: alone %.1f us per launch; beside %.1f us per launch (the other chain %.1f)\n",
+           dummies, alone * 1e3 / len, ta * 1e3 / len, tb * 1e3 / len);
     CK(hipStreamDestroy(a));
     CK(hipStreamDestroy(b));
     for (int i = 0; i < dummies; i++) CK(hipStreamDestroy(d[i]));
