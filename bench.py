@@ -349,7 +349,8 @@ def main():
             leg_total, leg_first = world * leg_n, rank * leg_n
         # ... and below 2^20 pairs only every fourth MSM carries the events (four records cost a 0.5 ms step 12 %: 2^16 0.53 ms per step
         # against 0.47 without); the kernel's average duration is then over those launches of the timed region
-        eng.set_option("timings_every", 1 if leg_n >= (1 << 20) else 4)
+        every = 1 if leg_n >= (1 << 20) else 4
+        eng.set_option("timings_every", every)
         # ---- synthetic inputs, resident in HBM -----------------------------------------------------------
         d_points = torch.empty((leg_n, info.aff_bytes), dtype=torch.uint8, device="cuda")
         eng.gen_points(curve, seed, leg_n, d_points, first=leg_first)            # P_i = [s_i]G, uniform over the subgroup
@@ -385,7 +386,10 @@ def main():
                     if in_exchange is not None:
                         res = xchg.finish(in_exchange)
                     in_exchange = started
-                if acc is not None:
+                # (only the sampled steps are asked for their events: the engine's sample counter is reset right before the timed loop, so
+                # submit number i carries events iff i is a multiple of `every` -- a last_timings() call per step is ~15 us of Python and
+                # ctypes on the thread that feeds a 0.45 ms step)
+                if acc is not None and i % every == 0:
                     t = eng.last_timings()                      # HIP events recorded on the engine's stream (zeros: not a sampled step)
                     if t["total"] > 0.0:
                         for key, v in t.items():
@@ -402,6 +406,7 @@ def main():
         run_steps(args.warmup)
         acc = {}
         fn_fence()
+        eng.enable_timings(2)            # (resets the engine's sample counter: the timed loop's submit 0 is a sampled one)
         t0 = time.perf_counter()
         res = run_steps(args.steps, acc)
         fn_fence()
