@@ -105,6 +105,14 @@ struct GatherLds {
 };
 template <class F, bool INTO = false>
 __global__ void __launch_bounds__(ACCUM_BLOCK, (sizeof(XYZZ<F>) > 256 ? 1 : CTT_ACCUM_WAVES)) k_accum(AccumArgs<F> a) {
+#if defined(CTT_G2_PHASE_NOPS) && CTT_G2_PHASE_NOPS > 0
+  // Shifts the BLS12-381 G2 kernel's instruction stream by 4 bytes per s_nop: its speed depends on the 8-byte phase of its multiply-adds
+  // (msm_bodies.h accum_body_z; tools/phase_stats.py says which phase a build has).  Not needed for the shipped sources (73 % at 0 mod 8).
+  if constexpr (IsFp2<F>::value && F::UNSAT) {
+#pragma unroll
+    for (int i = 0; i < CTT_G2_PHASE_NOPS; i++) asm volatile("s_nop 0");
+  }
+#endif
   if constexpr (F::UNSAT && !IsFp2<F>::value) {   // (not the quadratic extension: msm_bodies.h accum_body_z has the measurement)
     __shared__ uint4 stage[GatherLds<F>::NCH][ACCUM_BLOCK];
     GatherLds<F> gq{stage};

@@ -359,21 +359,19 @@ CTT_HD void accum_body_xyzz(const AccumArgs<F>& a, uint32_t w, uint32_t g, G& gq
 
 // the accumulate body in the X, Y + ZZ/ZZZ-holder form (ec.h xyzz_madd_core): used for the quadratic-extension fields.
 // Everything is read ON DEMAND here -- the boundary of the current bucket, the walk over empty buckets, the entry word, then the record:
-// four dependent reads of ~1 us per iteration, 12.4 % of the wave cycles parked on s_waitcnt, 80.6 % VALU-busy with ONE wave per SIMD
-// (483 of 512 registers).  Three ways of hiding those reads were built, and every one measured ~10 % SLOWER on the same box:
-//   round 3   the pipelined loop of accum_body_xyzz (record collected before the boundary block: 57 more registers live across it):
-//             9.47 -> 10.53 ms per MSM at 2^20;
-//   round 6a  the record delivered into LDS by global_load_lds, loop order and register count unchanged (485 registers, 0 scratch,
-//             +1.3 % instructions, the request in front of the 18093 multiply-adds in the ISA): accumulate 8.48 -> 9.17 ms under the
-//             counters, and 17.5 % of the wave cycles parked instead of 12.4 % (profiles/g2_gather_r06.txt; the instruction cache hits
-//             99.9 % in both);
-//   round 6b  no LDS at all: the entry words of pos + 1 / pos + 2 and BucketWalk's look-ahead boundary in three more registers, only the
-//             record read on demand: accumulate 7.99 -> 8.72 ms at 2^20, 2.39 -> 2.65 at 2^18, 0.63 -> 0.71 at 2^16 (same-box A/B against
-//             the round-5 library, two repetitions, profiles/g2_gather_r06.txt).
-// Same arithmetic, same instruction count, fewer exposed reads -- and slower each time.  One guess -- the waves of a CU stop meeting at a
-// wait at the top of every iteration, and the ~220 KB body is fetched through a 64 KB instruction cache that two CUs share -- was tested
-// (round 6c): the four waves of a CU as ONE workgroup with a barrier per iteration.  Slower still (accumulate 7.9 -> 8.9 ms at 2^20, 2.4 -> 5.3
-// at 2^18): it is not that.  The cause is open; EXPERIMENTS.md Part I R6.3 has the counters of every form.  The on-demand loop stays.
+// 12.4 % of the wave cycles parked on s_waitcnt, 80.6 % VALU-busy with ONE wave per SIMD (483 of 512 registers).
+// Round 3 (pipelined loop) and round 6 (record into LDS with the loop order unchanged; entry words and bucket boundaries one step ahead in
+// registers; four waves of a CU in lockstep; a staggered start) each measured ~10 % SLOWER -- and round 6 found out why, and it is not the
+// loop: THE KERNEL'S SPEED DEPENDS ON THE 8-BYTE PHASE OF ITS INSTRUCTION STREAM.  With one wave per SIMD an 8-byte instruction whose address
+// is 4 mod 8 costs extra issue time; in the shipped code object 73 % of the 18 097 v_mad_u64_u32 of an iteration sit at 0 mod 8, and every
+// one of those variants happened to shift the stream by an odd number of dwords (27 % at 0 mod 8).  The proof is a build that differs from
+// the shipped one by s_nop instructions at the kernel's entry only: same phase 7.76 ms per launch at 2^20, flipped phase 8.65 ms (+11.5 %)
+// (tools/phase_stats.py, profiles/g2_gather_r06.txt).  Re-measured at the good phase, the record-into-LDS form is LEVEL with this loop
+// (9.42 against 9.39 ms per MSM at 2^20, 2.96 against 3.03 at 2^18) and the register look-ahead form 1.5 % faster (9.26 against 9.40):
+// the parked cycles are not the dependent reads.  This loop stays; hip_backend.h k_accum has the knob that flips the phase
+// (CTT_G2_PHASE_NOPS) and __graft_entry__.build() reports the aligned share of the built object, so that a change that flips it is seen.
+// The kernels with two or more waves per SIMD (every other curve) do not care: their multiply-adds are split 50 / 50 and a shifted stream
+// measures the same.
 template <class F, class Z, bool INTO = false>
 CTT_HD void accum_body_z(const AccumArgs<F>& a, uint32_t w, uint32_t g, Z& z) {
   if (g >= a.G) return;

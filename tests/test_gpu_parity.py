@@ -747,13 +747,18 @@ def test_api_misuse_returns_error_codes(dev, torch_cuda):
     t1 = dev.submit(name, ds, dp, n)
     t2 = dev.submit(name, ds, dp, n)
     t3 = dev.submit(name, ds, dp, n)
+    from constantine_amd import _lib
+    L = _lib.lib()
     with pytest.raises(RuntimeError):
         dev.submit(name, ds, dp, n)              # fourth ticket
+    assert L.ctt_hip_last_error() == -5          # ERR_BUSY (round 6; -1 before): "finish a ticket, or retry" -- not "bad arguments"
     with pytest.raises(RuntimeError):
         dev.msm(name, ds, dp, n)                 # blocking call needs a free slot
+    assert L.ctt_hip_last_error() == -5
     assert bytes(dev.finish(t1)) == expect
     with pytest.raises(RuntimeError):
         dev.finish(t1)                           # finished already
+    assert L.ctt_hip_last_error() == -1          # a bare refusal is "bad arguments", and no stale -5 survives into it
     assert bytes(dev.finish(t3)) == expect       # (any order)
     assert bytes(dev.finish(t2)) == expect
     assert bytes(dev.msm(name, ds, dp, n)) == expect
