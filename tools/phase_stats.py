@@ -36,13 +36,16 @@ def stats(obj):
         if m:
             addrs.append((int(m.group(2), 16), m.group(1)))
     mad, all8 = collections.Counter(), collections.Counter()
-    for (a, op), (b, _) in zip(addrs, addrs[1:]):
+    windows = collections.defaultdict(lambda: [0, 0])      # per 1000 instructions: multiply-adds at 0 / 4 mod 8
+    for i, ((a, op), (b, _)) in enumerate(zip(addrs, addrs[1:])):
         if b - a == 8:
             all8[a % 8] += 1
             if op == "v_mad_u64_u32":
                 mad[a % 8] += 1
+                windows[i // 1000][0 if a % 8 == 0 else 1] += 1
     return {"instructions": len(addrs), "mad_at_0": mad[0], "mad_at_4": mad[4], "aligned_frac": mad[0] / max(1, mad[0] + mad[4]),
-            "all8_at_0": all8[0], "all8_at_4": all8[4]}
+            "all8_at_0": all8[0], "all8_at_4": all8[4], "windows": [tuple(windows[k]) for k in sorted(windows)],
+            "best_by_window": sum(max(v) for v in windows.values()) / max(1, mad[0] + mad[4])}
 
 
 if __name__ == "__main__":
@@ -54,3 +57,6 @@ if __name__ == "__main__":
             continue
         print(f"{(tag or os.path.basename(obj)):28s} {s['instructions']:6d} instructions; v_mad_u64_u32 at 0 mod 8: {s['mad_at_0']:6d} ({100 * s['aligned_frac']:.0f} %), at 4 mod 8: {s['mad_at_4']:6d};"
               f" all 8-byte instructions {s['all8_at_0']} / {s['all8_at_4']}")
+        if os.environ.get("WINDOWS") == "1":
+            print("    per 1000 instructions, multiply-adds at 0 / 4 mod 8: " + " ".join(f"{a}/{b}" for a, b in s["windows"]) +
+                  f"   (choosing the phase per window would give {100 * s['best_by_window']:.0f} %)")
