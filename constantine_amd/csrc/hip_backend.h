@@ -337,7 +337,12 @@ __global__ void __launch_bounds__(EC_BLOCK) k_window_groups(const XYZZ<F>* out, 
 
 // a narrow pass of the bucket reduction: four lanes per addition (xyzz_add_quad)
 template <class F>
-__global__ void __launch_bounds__(EC_BLOCK) k_pyr_quad(PyrArgs<F> a, uint32_t ntasks) {
+__global__ void __launch_bounds__(EC_BLOCK) k_pyr_quad(PyrArgs<F> a, uint32_t ntasks, uint32_t prio) {
+  // The narrow passes are a chain of short dependent launches of few waves which, when MSMs are pipelined, share their SIMDs with the next MSM's
+  // sort and accumulate kernels; at equal wave priority the chain -- the critical path of a small MSM -- stretches.  s_setprio 3 lets these waves
+  // issue first: BLS12-381 G1 -5 ... -6 % per MSM at 2^14 ... 2^18 pairs with two in flight, BN254 -5 ... -9 % at 2^16 ... 2^19; level from 2^20 on,
+  // and the host switches it off there and for the curves it does not help (Curve::NARROW_PRIO_LOG2N, profiles/wave_priority_r06.txt).
+  if (prio) __builtin_amdgcn_s_setprio(3);
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t t = lane >> 2;
   const int role = (int)(lane & 3u);
@@ -784,11 +789,14 @@ struct HipBackend {
     hipLaunchKernelGGL(k_window_groups<F>, dim3(W, gy), dim3(EC_BLOCK), 0, cur(), out, wsum, c, h, ngrp);
     HIP_CHECK(hipGetLastError());
   }
+  // raised wave priority for the narrow reduction passes of the MSM being submitted (k_pyr_quad): the pipeline decides per curve and size
+  bool narrow_prio = false;
+  void narrow_priority(bool on) { narrow_prio = on; }
   template <class F>
   void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
     // few tasks left: four lanes per addition (the chip is mostly idle, the addition is 3.5x shallower)
     if (pyr_is_narrow(ntasks, W)) {
-      hipLaunchKernelGGL(k_pyr_quad<F>, grid2(ntasks * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, ntasks);
+      hipLaunchKernelGGL(k_pyr_quad<F>, grid2(ntasks * 4u, EC_BLOCK, W), dim3(EC_BLOCK), 0, cur(), a, ntasks, narrow_prio ? 1u : 0u);
       HIP_CHECK(hipGetLastError());
       return;
     }

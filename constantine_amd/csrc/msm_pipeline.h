@@ -704,6 +704,7 @@ struct MsmEngine {
     static const bool wide_early = !(getenv("CTT_HIP_MSM_WIDE_EARLY") && atoi(getenv("CTT_HIP_MSM_WIDE_EARLY")) == 0);
     bool forked = forked_early, marked = forked_early && bk.partitioned();   // (partitioned: submit() marked behind the merge)
     const bool first_pass_on_tail = opt.pyr0_tail == 1 && p.n <= (1u << 17) && !p.merged;   // (MsmOptions::pyr0_tail: measured, off)
+    bk.narrow_priority(C::NARROW_PRIO_LOG2N > 0 && p.n <= (1u << C::NARROW_PRIO_LOG2N));
     for (int pass = 0; pass <= p.c - 2; pass++) {
       PyrArgs<FD> pa{d_buckets, d_pyr, d_q, d_out, B, p.c, pass, 1u};
       const uint32_t ntasks = pyr_pass_tasks(B, p.c, pass);

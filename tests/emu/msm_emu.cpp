@@ -193,6 +193,7 @@ struct EmuBackend {
     for (uint32_t w = 0; w < W; w++)
       for (int g = 0; g < ngrp; g++) wsum[(size_t)w * ngrp + g] = window_group_sum_body<F>(out + (size_t)w * c, c, h, g);
   }
+  void narrow_priority(bool) {}   // (wave priority of the narrow passes: nothing to emulate)
   template <class F>
   void launch_pyr(const PyrArgs<F>& a, uint32_t W, uint32_t ntasks) {
     // a pass reads only what earlier passes wrote, except the in-place halving q[t] += q[t+n] (disjoint t)
