@@ -40,10 +40,10 @@ cp "$OUT/hbm_traffic_k_accum.json" profiles/hbm_traffic_k_accum.json
 timeout 600 python bench.py > "$OUT/bench_$TAG.json" 2> "$OUT/bench.err"
 
 # kernel trace + stats (rocpd database, summarised by tools/kernel_timeline.py)
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o p -- python "$REPO/bench.py" --steps 10 --warmup 2 \
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o p -- python "$REPO/bench.py" --steps 50 --warmup 5 \
     --no-cpu-baseline --no-latency > "$OUT/bench_${TAG}_under_rocprof.json" 2>> "$OUT/prof.log" )
 DB=$(find "$OUT/prof" -name "*.db" | head -1)
-python tools/kernel_timeline.py "$DB" 2 > "$OUT/rocprof_${TAG}_kernel_stats.txt" 2>> "$OUT/prof.log"   # (2: the warm-up MSMs are left out of the averages)
+python tools/kernel_timeline.py "$DB" 5 > "$OUT/rocprof_${TAG}_kernel_stats.txt" 2>> "$OUT/prof.log"   # (5: the warm-up MSMs are left out of the averages; the same steps / warm-up as the un-profiled line above, so that the two k_accum averages are comparable)
 
 
 # SQ counters of the accumulate kernel (own passes, kernel-trace only) for the headline and the 254/255-bit fields,
