@@ -35,12 +35,16 @@ static constexpr uint32_t KEY_NONE = 0xffffffffu;
 // chip busy, measured on MI355X (profiles/): what the window-size cost model (msm_pipeline.h choose_window_bits) ranks plans by.
 // NARROW_PRIO_LOG2N: the narrow reduction passes run at raised wave priority (hip_backend.h k_pyr_quad) for MSMs of up to 2^this pairs, 0 = never;
 // measured per curve (profiles/wave_priority_r06.txt: it helps BLS12-381 G1 and BN254 up to 2^19, does nothing for G2 and costs Pallas 3 % at 2^16).
-struct Bls12381G1 { using F = Fp<BLS12_381_Fp>; using FD = FpU<BLS12_381_Fp_U>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 0; static constexpr double ACC_NS = 0.142, RED_NS = 0.26; static constexpr int NARROW_PRIO_LOG2N = 19; };
-struct Bls12381G2 { using F = Fp2<Fp<BLS12_381_Fp>>; using FD = Fp2<FpU<BLS12_381_Fp_U>>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 1; static constexpr double ACC_NS = 0.467, RED_NS = 1.1; static constexpr int NARROW_PRIO_LOG2N = 0; };
-struct Bn254G1 { using F = Fp<BN254_Fp>; using FD = FpU<BN254_Fp_U>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; static constexpr double ACC_NS = 0.0685, RED_NS = 0.12; static constexpr int NARROW_PRIO_LOG2N = 19; };
-struct Bn254G2 { using F = Fp2<Fp<BN254_Fp>>; using FD = F; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 3; static constexpr double ACC_NS = 0.5, RED_NS = 1.2; static constexpr int NARROW_PRIO_LOG2N = 0; };
-struct PallasEc { using F = Fp<Pallas_Fp>; using FD = FpU<Pallas_Fp_U>; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; static constexpr double ACC_NS = 0.056, RED_NS = 0.10; static constexpr int NARROW_PRIO_LOG2N = 0; };
-struct VestaEc { using F = Fp<Vesta_Fp>; using FD = FpU<Vesta_Fp_U>; using Fr = Fp<Pallas_Fp>; static constexpr int BITS = 255; static constexpr int ID = 5; static constexpr double ACC_NS = 0.056, RED_NS = 0.10; static constexpr int NARROW_PRIO_LOG2N = 0; };
+// WHOLE_TAIL_LOG2N: from 2^this pairs on the accumulation of a pipelined MSM waits for the WHOLE tail of the previous one instead of its wide passes only
+// (msm_pipeline.h accumulate_pairs), 0 = never: the accumulate kernels of the 9-limb curves own every register of the chip (4 waves x 128), a narrow pass
+// beside them crawls (2 ms instead of 7 us) and costs the accumulation 19 % -- Pallas / Vesta 2^22 5.58 -> 5.02 ms per MSM, BN254 2^21 3.03 -> 2.76
+// (profiles/whole_tail_wait_r06.txt); BLS12-381 G1 leaves registers free and loses 5-19 % when made to wait.
+struct Bls12381G1 { using F = Fp<BLS12_381_Fp>; using FD = FpU<BLS12_381_Fp_U>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 0; static constexpr double ACC_NS = 0.142, RED_NS = 0.26; static constexpr int NARROW_PRIO_LOG2N = 19; static constexpr int WHOLE_TAIL_LOG2N = 0; };
+struct Bls12381G2 { using F = Fp2<Fp<BLS12_381_Fp>>; using FD = Fp2<FpU<BLS12_381_Fp_U>>; using Fr = Fp<BLS12_381_Fr>; static constexpr int BITS = 255; static constexpr int ID = 1; static constexpr double ACC_NS = 0.467, RED_NS = 1.1; static constexpr int NARROW_PRIO_LOG2N = 0; static constexpr int WHOLE_TAIL_LOG2N = 0; };
+struct Bn254G1 { using F = Fp<BN254_Fp>; using FD = FpU<BN254_Fp_U>; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 2; static constexpr double ACC_NS = 0.0685, RED_NS = 0.12; static constexpr int NARROW_PRIO_LOG2N = 19; static constexpr int WHOLE_TAIL_LOG2N = 21; };
+struct Bn254G2 { using F = Fp2<Fp<BN254_Fp>>; using FD = F; using Fr = Fp<BN254_Fr>; static constexpr int BITS = 254; static constexpr int ID = 3; static constexpr double ACC_NS = 0.5, RED_NS = 1.2; static constexpr int NARROW_PRIO_LOG2N = 0; static constexpr int WHOLE_TAIL_LOG2N = 0; };
+struct PallasEc { using F = Fp<Pallas_Fp>; using FD = FpU<Pallas_Fp_U>; using Fr = Fp<Vesta_Fp>; static constexpr int BITS = 255; static constexpr int ID = 4; static constexpr double ACC_NS = 0.056, RED_NS = 0.10; static constexpr int NARROW_PRIO_LOG2N = 0; static constexpr int WHOLE_TAIL_LOG2N = 21; };
+struct VestaEc { using F = Fp<Vesta_Fp>; using FD = FpU<Vesta_Fp_U>; using Fr = Fp<Pallas_Fp>; static constexpr int BITS = 255; static constexpr int ID = 5; static constexpr double ACC_NS = 0.056, RED_NS = 0.10; static constexpr int NARROW_PRIO_LOG2N = 0; static constexpr int WHOLE_TAIL_LOG2N = 21; };
 
 // ---------------------------------------------------------------------------------------------
 // Booth signed digits

@@ -628,7 +628,9 @@ struct MsmEngine {
     // start of this MSM's reduction (reduce_buckets), the first kernel that writes what the tail still reads.
     const uint64_t accum_waves = (uint64_t)W * ((p.G + 63u) / 64u);
     // (partitioned chip, HipBackend::partitioned: the tail stream has compute units of its own -- nothing to wait for, no slots to leave)
-    if (!bk.partitioned() && accum_waves + tail_min_free_waves() > (uint64_t)opt.lanes / 64u) bk.tail_wait();
+    // (Curve::WHOLE_TAIL_LOG2N: large MSMs of the curves whose accumulate kernel owns every register wait for the whole tail whatever the grid leaves free)
+    const bool whole_tail = C::WHOLE_TAIL_LOG2N > 0 && p.n >= (1u << C::WHOLE_TAIL_LOG2N);
+    if (!bk.partitioned() && (whole_tail || accum_waves + tail_min_free_waves() > (uint64_t)opt.lanes / 64u)) bk.tail_wait();
     bk.wide_wait();   // (nothing to wait for unless the previous reduction put wide passes on the tail stream)
     bk.stage_begin(sl, ST_ACCUM);
     st.d_buckets = d_buckets;
