@@ -6,8 +6,8 @@
 --strip-asm-nops   hipcc pads every inline-asm statement whose result the next instruction reads with one `s_nop 0`: its hazard
     recogniser cannot see inside the statement and assumes a producer with a partial-dword destination (dst_sel forwarding, one wait
     state).  The statements of this library hold full-dword v_mad_u64_u32 / add chains only, so the pad guards nothing.  With two waves
-    per SIMD the no-op hides behind the other wave's arithmetic most of the time; removing the 640 of the BLS12-381 G1 accumulate
-    kernel measures -1 % on that kernel (profiles/asm_pass_r06.txt).  Only `s_nop 0` lines that directly follow `;;#ASMEND` inside
+    per SIMD the no-op hides behind the other wave's arithmetic most of the time; removing them measures -1.7 % per MSM for BLS12-381 G1
+    at 2^20 and -3.1 % for BN254 at 2^22 (profiles/asm_pass_r06.txt).  Only `s_nop 0` lines that directly follow `;;#ASMEND` inside
     the named functions are removed; no-ops the compiler placed for hazards between its own instructions stay.
 
 --align   keeps every 8-byte instruction on an 8-byte boundary.  With ONE wave per SIMD -- the BLS12-381 G2 kernels, 483 of 512
